@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the `image` hot path on MI355X.
+
+Metric (BASELINE.json): Gbases/s (+ samples/s) for `varKoder image`, k=7, 150 bp reads.
+Workload at N=1 = BASELINE.json configs[1]: 1000 synthetic samples x 1M 150 bp reads,
+k=7 varKode (91x91), 1x MI355X.  One "step" = one pass of the whole hot path
+(FASTQ text resident in HBM -> k-mer histograms -> uint8 images) over that batch.
+
+320 GB of distinct text does not fit one GPU, so -- as SURVEY.md 8d prescribes -- a pool
+of `--pool` distinct samples (default 64 = 20.5 GB) is generated on the device and the
+batch of 1000 cycles through it; every batch entry still gets its own histogram and
+image.  Generation is outside the timed region.
+
+N>1: one process per GPU (torchrun), samples shard across ranks with no data-path
+collective (weak scaling: every rank runs the same per-GPU batch on its own pool);
+the only collective is the MAX-reduce of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=1000, help="samples per GPU per step")
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--readlen", type=int, default=150)
+    ap.add_argument("--k", type=int, default=7)
+    ap.add_argument("--mapping", default="varKode")
+    ap.add_argument("--pool", type=int, default=64, help="distinct samples resident in HBM")
+    ap.add_argument("--dist", type=int, default=0, help="0 uniform, 1 GC-skew + homopolymers")
+    ap.add_argument("--parts", type=int, default=0, help="workgroups per sample (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
+    """The oracle's C restatement ("port") timed on this host's cores on a bounded sample
+    of the same workload: whole samples of the device-generated pool, copied back."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    from varkoder_amd.mapping import pixel_lut, side
+    oracle.lib()
+    lut = pixel_lut(args.k, args.mapping)
+    n = side(args.k, args.mapping)
+    nbuf = min(4, len(offs))
+    bufs = [fastq_dev[int(offs[i]):int(offs[i]) + int(lens[i])].cpu().numpy() for i in range(nbuf)]
+    bases_per_sample = args.reads * args.readlen
+    cores = min(os.cpu_count() or 1, 16)
+
+    def one(i):
+        img, nwin, st = oracle.fastq_to_image(bufs[i % nbuf], args.k, lut, n * n)
+        assert st == 0
+        return nwin
+
+    # single thread first (one sample), to size the multi-thread run
+    t0 = time.perf_counter()
+    one(0)
+    t1 = time.perf_counter() - t0
+    per_thread = max(1, int(seconds / max(t1, 1e-3)))
+    nsamp = min(cores * per_thread, 64 * cores)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(nsamp)))
+    dt = time.perf_counter() - t0
+    return {"value": nsamp * bases_per_sample / dt / 1e9, "unit": "Gbases/s", "cores": cores,
+            "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9,
+            "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
+                      f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from varkoder_amd.engine import ImageEngine
+    eng = ImageEngine(k=args.k, mapping=args.mapping, device=local_rank)
+
+    pool = min(args.pool, args.samples)
+    fastq, poffs, plens = eng.synth(rank * pool, pool, args.reads, args.readlen, dist=args.dist)
+    idx = np.arange(args.samples) % pool
+    offs, lens = poffs[idx].copy(), plens[idx].copy()
+    ncode = 4 ** args.k
+    hist = torch.empty((args.samples, ncode), dtype=torch.int32, device=dev)
+    status = torch.empty((args.samples,), dtype=torch.int32, device=dev)
+    img = torch.empty((args.samples, eng.side, eng.side), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(e=None):
+        if e:
+            e[0].record()
+        eng.count(fastq, offs, lens, parts=args.parts, hist=hist, status=status)
+        if e:
+            e[1].record()
+        eng.images(hist, img=img)
+        if e:
+            e[2].record()
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    bad = int((status != 0).sum().item())
+    count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    image_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    if rank == 0:
+        bases_per_step = args.samples * args.reads * args.readlen * world
+        value = bases_per_step * args.steps / elapsed / 1e9
+        fastq_bytes = int(lens[0])
+        # algorithmic bytes of the dominant kernel (vk_count_kernel), SURVEY 8d:
+        # FASTQ text read once + the 4^k u32 histogram written once, per sample
+        alg_bytes = args.samples * (fastq_bytes + 4 * ncode)
+        achieved = alg_bytes / (count_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Gbases/s for `varKoder image` k=%d, %d bp reads" % (args.k, args.readlen),
+            "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "samples_per_s": args.samples * world * args.steps / elapsed,
+            "config": {"workload": "%d synthetic samples x %d x %d bp reads per GPU, k=%d %s (%dx%d), "
+                                   "FASTQ text resident in HBM" % (args.samples, args.reads, args.readlen,
+                                                                   args.k, args.mapping, eng.side, eng.side),
+                       "samples_per_gpu": args.samples, "reads_per_sample": args.reads,
+                       "read_len": args.readlen, "k": args.k, "mapping": args.mapping,
+                       "distinct_samples_in_hbm": pool, "base_distribution": args.dist,
+                       "fastq_bytes_per_sample": fastq_bytes, "parallelism": "samples sharded x%d" % world,
+                       "count_launch": eng.last_count_launch()},
+            "kernel_ms": {"vk_count_kernel(+check)": count_ms, "vk_image_kernel": image_ms},
+            "bad_status_samples": bad,
+            "roofline": {"bound": "hbm", "kernel": "vk_count_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": count_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(eng, fastq, poffs, plens, args, args.cpu_seconds)
+            except Exception as e:  # the baseline is a reported side figure, never the product path
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+    if bad:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+/*
+ * vkimg.h -- C ABI of libvkimg_hip.so: varKoder's `image` hot path on MI355X (gfx950).
+ *
+ * The reference (brunoasm/varKoder) has no FFI layer: the path sits behind two
+ * Python functions that shell out to `dsk` / `dsk2ascii`.  Each
+ * entry point below names the reference interface it replaces.  Plain pointers
+ * and sizes only; status codes, never exceptions; caller-allocated buffers.
+ *
+ * Conventions
+ *   - k in [5, 9]  (varKoder/commands/image.py:1209-1210).
+ *   - k-mer code: bases A0 C1 G2 T3, code = sum_i b_i * 4^(k-1-i) (first base
+ *     most significant), so codes sort like the k-mer strings.
+ *   - hist[4^k] (u32): FORWARD-strand window counts.  The canonical class count
+ *     dsk reports for {s, rc(s)} is hist[s] + hist[rc(s)] (hist[s] for a
+ *     palindrome); vk_image_* performs that merge.
+ *   - pix[4^k] (u32): image pixel index (row-major, row 0 on top) of every code,
+ *     i.e. (side-1-y)*side + x of the reference's mapping table
+ *     (core/utils.py:152-217, image.py:906-913).
+ *   - "d_" pointers are device (HBM) addresses of the context's GPU; the others
+ *     are host addresses.  FASTQ samples on the device must start at 16-byte
+ *     aligned addresses and the buffer must be readable up to the 16-byte
+ *     rounded end of the last sample.
+ *   - All work is enqueued on the context's stream; *_host calls synchronise
+ *     before returning, *_device calls do not.
+ */
+#ifndef VKIMG_H
+#define VKIMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_OK 0
+#define VK_EINVAL 1      /* bad argument (k, null pointer, alignment) */
+#define VK_EHIP 2        /* a HIP runtime call failed; see vk_last_hip_error */
+#define VK_ENOMAP 3      /* vk_set_mapping not called for this k */
+#define VK_EFORMAT 4     /* FASTQ framing inconsistent (per-sample status word) */
+#define VK_ENOMEM 5
+
+/* per-sample status bits written by the count stage */
+#define VK_ST_BAD_START 1u     /* first byte of a non-empty sample is not '@' */
+#define VK_ST_BAD_PHASE 2u     /* line count mod 4 inconsistent between byte ranges / at EOF */
+
+typedef struct vk_ctx vk_ctx;
+
+int vk_abi_version(void);
+const char* vk_strerror(int status);
+/* hipGetErrorString of the last failing HIP call on this context ("" if none) */
+const char* vk_last_hip_error(const vk_ctx* ctx);
+
+/* Context: one per process per GPU.  own_stream != 0: the library creates its own
+ * non-blocking stream (`stream` ignored); own_stream == 0: all work is enqueued on the
+ * caller's hipStream_t `stream` (NULL = the device's default stream), so that it
+ * orders with the caller's other work, e.g. a PyTorch stream. */
+int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out);
+void vk_ctx_destroy(vk_ctx* ctx);
+int vk_ctx_sync(vk_ctx* ctx);
+
+/* Replaces get_kmer_mapping(k, method) (core/utils.py:152-171): installs the
+ * code->pixel table for k.  pix == NULL selects the CGR closed form of
+ * get_cgr (core/utils.py:174-217; npix must be 4^k); otherwise pix[4^k] is a
+ * host table (varKode LUT) with every entry < npix. */
+int vk_set_mapping(vk_ctx* ctx, int k, const uint32_t* pix, uint32_t npix);
+
+/* Replaces count_kmers() = `dsk -kmer-size k -abundance-min 1 -file IN`
+ * (commands/image.py:727-806, argv :771-790) for a batch of samples resident in
+ * HBM.  Sample i is the FASTQ text d_fastq[offsets[i] .. offsets[i]+lengths[i]).
+ * d_hist[nsamples][4^k] receives forward-strand counts, d_status[nsamples] the
+ * VK_ST_* bits.  parts_per_sample = 0 lets the library choose how many
+ * workgroups split one sample. */
+int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
+                    const uint64_t* lengths, uint32_t nsamples, int k,
+                    uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status);
+
+/* Replaces make_image()'s arithmetic = `dsk2ascii` dump + join/groupby +
+ * count+1 scatter + 256-quantile rank binning (commands/image.py:864-919) for a
+ * batch of histograms.  d_img[nsamples][npix] receives the uint8 pixels. */
+int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int k,
+                    uint8_t* d_img);
+
+/* Both stages back to back (run_clean2img steps D+E, commands/image.py:1054-1127). */
+int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
+                             const uint64_t* lengths, uint32_t nsamples, int k,
+                             uint32_t parts_per_sample, uint32_t* d_hist,
+                             uint32_t* d_status, uint8_t* d_img);
+
+/* Host-buffer conveniences (one sample): H2D copy, kernels, D2H copy, sync.
+ * vk_count_host returns VK_EFORMAT when the sample's status word is non-zero
+ * (hist is still written). */
+int vk_count_host(vk_ctx* ctx, const uint8_t* fastq, size_t nbytes, int k, uint32_t* hist,
+                  uint32_t* status);
+int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img);
+
+/* Synthetic FASTQ of BASELINE.md section 4, written straight into HBM: samples
+ * sample0 .. sample0+nsamples-1, `reads` reads of `readlen` bases each, record =
+ * "@sSSSSS.RRRRRRR\n" + bases + "\n+\n" + 'I'*readlen + "\n" (2*readlen+20 bytes;
+ * 320 at readlen 150).  dist 0 = uniform ACGT, 1 = GC-skewed + homopolymer
+ * reads; N injected at ~1e-3 per base.  Sample j starts at j*reads*(2*readlen+20).
+ * varkoder_amd/synth.py is the bit-identical host generator. */
+int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t nsamples,
+                          uint32_t reads, uint32_t readlen, uint64_t seed, int dist);
+
+/* Introspection used by bench.py / tests: workgroups and LDS bytes of the last
+ * vk_count_device launch. */
+int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKIMG_H */

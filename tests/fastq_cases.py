@@ -1,0 +1,38 @@
+"""Hand-written FASTQ edge cases shared by the oracle tests and the GPU parity tests."""
+import numpy as np
+
+
+def rec(name, seq, qual=None, plus="+"):
+    q = qual if qual is not None else "I" * len(seq)
+    return f"@{name}\n{seq}\n{plus}\n{q}\n".encode()
+
+
+def rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(list(alphabet), size=n))
+
+
+def edge_cases():
+    rng = np.random.default_rng(7)
+    cases = {}
+    cases["empty"] = b""
+    cases["one_read"] = rec("r", "ACGTACGTACGTAAACCCGGGTTT")
+    cases["n_in_middle"] = rec("r", "ACGTACGTANACGTACGTACGT")
+    cases["len_k_minus_1"] = rec("r", "ACGTAC")          # k=7: nothing
+    cases["len_k"] = rec("r", "ACGTACG")
+    cases["lowercase"] = rec("r", "acgtacgtacgtnacgtacgtacg")
+    cases["mixed_case_iupac"] = rec("r", "ACGTRYKMacgtACGTACGTSWBDHVNACGTACGTAC")
+    cases["crlf"] = b"@r\r\nACGTACGTACGTACGT\r\n+\r\nIIIIIIIIIIIIIIII\r\n"
+    cases["no_final_newline"] = rec("a", "ACGTACGTACGTTTGA") + b"@b\nGGGGGGGGGGCCCCCCCCCC\n+\nIIIIIIIIIIIIIIIIIIII"
+    cases["qual_starts_at_plus"] = (rec("a", "ACGTACGTACGT", qual="@+@+@+@+@+@+") +
+                                    rec("b", "TTTTACGTAAAC", qual="+@+@+@+@+@+@", plus="+b") +
+                                    rec("c", "GATTACAGATTACA", qual="@IIIIIIIIIIIII"))
+    cases["palindromes_even_k"] = rec("p", "ACGTACGTACGTACGTAATTAATTGGCCGGCCGCGCGCGCATATATAT")
+    cases["poly_a"] = rec("p", "A" * 300)
+    cases["empty_read"] = rec("e", "") + rec("f", "ACGTACGTACGTACG")
+    cases["long_header"] = rec("h" * 700 + " ACGTACGTACGTACGT", "GATTACAGATTACAGATTACA")
+    cases["long_read"] = rec("long", rand_seq(rng, 20000))
+    cases["many_short"] = b"".join(rec(f"s{i}", rand_seq(rng, int(rng.integers(0, 24)), "ACGTN")) for i in range(3000))
+    cases["ragged"] = b"".join(rec(f"r{i} extra/1", rand_seq(rng, int(rng.integers(30, 260)), "ACGTACGTACGTN"))
+                               for i in range(4000))
+    cases["exact_64_multiple"] = b"".join(rec("%06d" % i, rand_seq(rng, 24)) for i in range(1024))  # 64 B records
+    return cases

@@ -1,0 +1,109 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+
+Integer / byte work: the bar is bit-exact equality.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import vectors
+from fastq_cases import edge_cases
+from oracle import oracle
+from varkoder_amd import synth
+from varkoder_amd.mapping import pixel_lut, side
+
+pytestmark = pytest.mark.gpu
+
+KS = (5, 6, 7, 8, 9)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_library_loaded_and_gpu_visible(engines):
+    import torch
+    assert torch.cuda.is_available()
+    eng = engines(7)
+    assert eng.L.vk_abi_version() == 1
+
+
+@pytest.mark.parametrize("k", KS)
+def test_count_edge_cases_match_oracle(engines, k):
+    eng = engines(k)
+    for name, fq in edge_cases().items():
+        want, nwin, st = oracle.count_fastq(fq, k)
+        got, status = eng.count_host(fq)
+        assert status == 0, (name, status)
+        assert st == 0, name
+        assert int(got.sum(dtype=np.uint64)) == nwin, name
+        assert np.array_equal(got, want), name
+
+
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("dist", (0, 1))
+def test_count_synthetic_batch_matches_oracle(engines, k, dist):
+    """Small parity set of SURVEY 8d: 8 samples x 10,000 reads x 150 bp, generated on the
+    host, counted in one batched launch (several workgroup splits)."""
+    eng = engines(k)
+    samples = [synth.sample_fastq(s, 10000, 150, dist=dist) for s in range(8)]
+    dev, offs, lens = eng.upload(samples)
+    want = np.stack([oracle.count_fastq(s, k)[0] for s in samples])
+    for parts in (0, 1, 3, 8):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any(), parts
+        got = hist.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), parts
+
+
+def test_device_generator_equals_host_generator(engines):
+    eng = engines(7)
+    for dist in (0, 1):
+        dev, offs, lens = eng.synth(5, 3, 2000, 150, dist=dist)
+        got = dev.cpu().numpy()
+        for j in range(3):
+            want = synth.sample_fastq(5 + j, 2000, 150, dist=dist)
+            o = int(offs[j])
+            assert np.array_equal(got[o:o + want.size], want), (dist, j)
+
+
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("mapping", ("cgr", "varKode"))
+def test_image_matches_reference_golden(engines, manifest, golden_small, k, mapping):
+    """Expected pixels were produced by the reference's own make_image (oracle/gen_golden.py)."""
+    eng = engines(k, mapping)
+    for dist in vectors.DISTS:
+        fwd = vectors.fwd_hist(k, dist)
+        img = eng.image_host(fwd)
+        key = f"k{k}_{mapping}_{dist}"
+        assert list(img.shape) == manifest["image_cases"][key]["shape"]
+        if key in golden_small:
+            assert np.array_equal(img, golden_small[key]), key
+        assert sha(img) == manifest["image_cases"][key]["sha256"], key
+
+
+@pytest.mark.parametrize("k,mapping", [(7, "cgr"), (7, "varKode"), (9, "cgr"), (5, "varKode")])
+def test_fastq_to_image_batch_matches_oracle(engines, k, mapping):
+    eng = engines(k, mapping)
+    samples = [synth.sample_fastq(100 + s, 3000 + 500 * s, 150, dist=s & 1) for s in range(5)]
+    dev, offs, lens = eng.upload(samples)
+    img, hist, status = eng.fastq_to_images(dev, offs, lens)
+    assert not status.cpu().numpy().any()
+    lut, n = pixel_lut(k, mapping), side(k, mapping)
+    got = img.cpu().numpy()
+    for i, s in enumerate(samples):
+        want, _, st = oracle.fastq_to_image(s, k, lut, n * n)
+        assert st == 0
+        assert np.array_equal(got[i].ravel(), want), i
+
+
+def test_bad_framing_sets_status(engines):
+    eng = engines(7)
+    good = synth.sample_fastq(1, 50, 150).tobytes()
+    _, st = eng.count_host(good[1:])            # does not start with '@'
+    assert st & 1
+    _, st = eng.count_host(good[:-200])         # truncated inside a record
+    assert st & 2
+    _, st = eng.count_host(good)
+    assert st == 0

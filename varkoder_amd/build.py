@@ -1,0 +1,39 @@
+"""Compile the HIP extension in-tree: varkoder_amd/libvkimg_hip.so (gfx950 only)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "vkimg.hip")
+OUT = os.path.join(HERE, "libvkimg_hip.so")
+INC = os.path.join(ROOT, "include")
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the HIP extension cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INC, "vkimg.h")))
+    return os.path.getmtime(OUT) < newest
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-I", INC, SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,856 @@
+// vkimg.hip -- HIP kernels (gfx950 / CDNA4) and the C ABI of include/vkimg.h.
+//
+// Hot path of varKoder's `image` command (reference: varKoder/commands/image.py
+// count_kmers :727-806 -> dsk, make_image :808-936 -> dsk2ascii + pandas/NumPy):
+//
+//   K1  vk_count_kernel   FASTQ text in HBM -> forward-strand k-mer histogram u32[4^k]
+//   K1c vk_check_kernel   line-phase consistency of the byte ranges -> status word
+//   K2  vk_image_kernel   strand merge + pixel scatter (count+1) + sort + 256-quantile
+//                         rank binning -> uint8 image
+//   vk_synth_kernel       synthetic FASTQ generator of BASELINE.md section 4
+//
+// Design notes live in DESIGN.md; the short version for K1:
+//   * one 1024-thread workgroup per (sample, byte-range part[, histogram part]);
+//     its 16 wavefronts run WITHOUT workgroup barriers in steady state: every
+//     wave streams its own contiguous byte range in 4 KiB pieces (4 coalesced
+//     16-B loads per lane, prefetched one piece ahead), transposes the piece
+//     through a private 4 KiB LDS slot so that each lane owns 64 contiguous
+//     bytes, and walks those bytes from registers;
+//   * FASTQ line phase (header/sequence/plus/quality) comes from a wave-level
+//     prefix sum of newline counts; the phase at a range start is recovered
+//     locally from the '@' / '+' framing, so byte ranges are independent;
+//   * k-mer windows are counted forward-strand only into an LDS histogram
+//     (ds_add_u32); the strand merge happens once per sample in K2;
+//   * 4^k u32 > LDS for k = 8, 9: the code space is split over 2^LOG_PARTS
+//     sibling workgroups that read the same bytes (kept on one XCD for L2 reuse).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "vkimg.h"
+
+namespace {
+
+constexpr int kWaves = 16;             // wavefronts per count workgroup
+constexpr int kCountThreads = kWaves * 64;
+constexpr int kPiece = 4096;           // bytes per wave iteration (64 lanes x 64 B)
+constexpr uint32_t kMaxBins = 16384;   // u32 LDS histogram bins per workgroup (64 KiB)
+
+// ---------------------------------------------------------------- helpers ----
+
+__device__ __forceinline__ uint32_t nl_flags(uint32_t w) {
+    // bit 7 of every byte that equals '\n' (exact, no borrow artefacts)
+    uint32_t z = w ^ 0x0A0A0A0Au;
+    uint32_t t = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;  // bit7 set iff byte != 0
+    return ~t & 0x80808080u;
+}
+
+__device__ __forceinline__ uint32_t nl_count16(uint4 v) {
+    return __popc(nl_flags(v.x)) + __popc(nl_flags(v.y)) + __popc(nl_flags(v.z)) + __popc(nl_flags(v.w));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wavefront execute in order; this only stops the
+    // compiler from moving LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+__device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// 16 bytes at sample offset `off`, zero for every byte at or beyond `lim`.
+// Requires the buffer to be readable up to the 16-byte rounded end (ABI contract).
+__device__ __forceinline__ uint4 load_granule(const uint8_t* sbase, uint64_t off, uint64_t lim) {
+    if (off + 16 <= lim) return *reinterpret_cast<const uint4*>(sbase + off);
+    if (off >= lim) return zero4();
+    uint4 v = *reinterpret_cast<const uint4*>(sbase + off);
+    uint32_t keep = static_cast<uint32_t>(lim - off);  // 1..15 valid bytes
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        int kb = static_cast<int>(keep) - 4 * d;
+        uint32_t m = kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
+        w[d] &= m;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Line phase (0 header, 1 sequence, 2 plus, 3 quality) of the line that contains
+// byte w0 > 0 of a 4-line FASTQ, recovered from the bytes at and after w0:
+// among four consecutive line starts exactly one is a header, and a line start l_i
+// is a header iff byte[l_i] == '@' and byte[l_{i+2}] == '+' (a quality line may
+// start with '@', but then l_{i+2} is a sequence line, which never starts with '+').
+// Falls back to counting the newlines of [0, w0) when fewer than six newlines
+// follow w0.  Wave-uniform; `slot` is this wave's private LDS scratch.
+__device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, uint64_t* slot, int lane) {
+    uint32_t n = 0;
+    uint64_t pos = w0;
+    while (n < 6 && pos < len) {
+        uint8_t b = (pos + lane < len) ? sbase[pos + lane] : 0;
+        unsigned long long m = __ballot(b == '\n');
+        while (m && n < 6) {
+            int j = __builtin_ctzll(m);
+            slot[n] = pos + j;
+            ++n;
+            m &= m - 1;
+        }
+        pos += 64;
+    }
+    wave_lds_fence();
+    for (uint32_t i = 0; i + 2 < n && i < 4; ++i) {
+        uint64_t li = slot[i] + 1, lj = slot[i + 2] + 1;
+        if (lj < len && sbase[li] == '@' && sbase[lj] == '+') {
+            wave_lds_fence();
+            return (3u - i) & 3u;  // the line holding w0 is line -1: phase (-1 - i) mod 4
+        }
+    }
+    wave_lds_fence();
+    // slow, always-correct path: count newlines before w0 (w0 is a multiple of 64)
+    uint32_t cnt = 0;
+    for (uint64_t off = static_cast<uint64_t>(lane) * 16; off + 16 <= w0; off += 1024)
+        cnt += nl_count16(*reinterpret_cast<const uint4*>(sbase + off));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+    return cnt & 3u;
+}
+
+// --------------------------------------------------------------- K1 count ----
+
+template <int K, int LOG_PARTS>
+__global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
+    const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+    const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t HPARTS = 1u << LOG_PARTS;
+    constexpr uint32_t BINS = NCODE >> LOG_PARTS;
+    constexpr uint32_t MASK = NCODE - 1u;
+    constexpr uint32_t PSHIFT = 2 * K - LOG_PARTS;
+    static_assert(BINS <= kMaxBins, "LDS histogram too large");
+
+    __shared__ uint32_t hist[BINS];
+    __shared__ uint4 stage[kWaves][kPiece / 16];
+
+    // block -> (unit = (sample, part), histogram part); the HPARTS siblings of a
+    // unit get block ids that differ by multiples of 8, i.e. share an XCD's L2.
+    const uint32_t bid = blockIdx.x;
+    const uint32_t grp = bid / (8u * HPARTS);
+    const uint32_t rem = bid % (8u * HPARTS);
+    const uint32_t hp = rem / 8u;
+    const uint32_t unit = grp * 8u + (rem % 8u);
+    if (unit >= nsamples * parts) return;  // whole workgroup, before any barrier
+    const uint32_t s = unit / parts;
+    const uint32_t part = unit % parts;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
+    __syncthreads();
+
+    const uint8_t* sbase = fastq + offs[s];
+    const uint64_t len = lens[s];
+    const uint64_t nblk = (len + 63) >> 6;
+    const uint64_t bwg = (nblk + parts - 1) / parts;
+    const uint64_t bw = (bwg + kWaves - 1) / kWaves;
+    uint64_t blk0 = static_cast<uint64_t>(part) * bwg + static_cast<uint64_t>(wave) * bw;
+    uint64_t blk1 = static_cast<uint64_t>(part) * bwg + umin64(static_cast<uint64_t>(wave + 1) * bw, bwg);
+    if (blk1 > nblk) blk1 = nblk;
+    const bool empty = blk0 >= blk1;
+    const uint64_t w0 = blk0 << 6;
+    const uint64_t w1 = empty ? w0 : umin64(blk1 << 6, len);
+
+    uint32_t ph_start = 0, ph = 0;
+    if (!empty) {
+        uint64_t* slot = reinterpret_cast<uint64_t*>(&stage[wave][0]);
+        if (w0 != 0) ph = sync_phase(sbase, w0, len, slot, lane);
+        ph_start = ph;
+
+        // halo: the 8 bytes before the range (zeros at the sample start)
+        uint32_t carry0 = 0, carry1 = 0;
+        if (w0 != 0) {
+            uint2 h = *reinterpret_cast<const uint2*>(sbase + w0 - 8);
+            carry0 = h.x;
+            carry1 = h.y;
+        }
+
+        const uint64_t npieces = (w1 - w0 + kPiece - 1) / kPiece;
+        uint4 r0, r1, r2, r3;
+        {
+            uint64_t p = w0 + static_cast<uint64_t>(lane) * 16;
+            r0 = load_granule(sbase, p, w1);
+            r1 = load_granule(sbase, p + 1024, w1);
+            r2 = load_granule(sbase, p + 2048, w1);
+            r3 = load_granule(sbase, p + 3072, w1);
+        }
+        for (uint64_t it = 0; it < npieces; ++it) {
+            // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
+            uint4* st = &stage[wave][0];
+            wave_lds_fence();
+            st[lane] = r0;
+            st[64 + lane] = r1;
+            st[128 + lane] = r2;
+            st[192 + lane] = r3;
+            wave_lds_fence();
+            uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
+            wave_lds_fence();
+            if (it + 1 < npieces) {  // prefetch the next piece under the walk
+                uint64_t p = w0 + (it + 1) * kPiece + static_cast<uint64_t>(lane) * 16;
+                r0 = load_granule(sbase, p, w1);
+                r1 = load_granule(sbase, p + 1024, w1);
+                r2 = load_granule(sbase, p + 2048, w1);
+                r3 = load_granule(sbase, p + 3072, w1);
+            }
+            uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                              q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+
+            // newline prefix -> line phase at the start of this lane's 64 bytes
+            uint32_t c = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c += __popc(nl_flags(d[q]));
+            uint32_t incl = c;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                uint32_t t = __shfl_up(incl, dd);
+                if (lane >= dd) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            uint32_t lph = ph + incl - c;  // only the low 2 bits matter
+
+            // the 8 bytes before this lane's block
+            uint32_t h0 = __shfl_up(d[14], 1), h1 = __shfl_up(d[15], 1);
+            if (lane == 0) { h0 = carry0; h1 = carry1; }
+            carry0 = __shfl(d[14], 63);
+            carry1 = __shfl(d[15], 63);
+
+            uint32_t fw = 0, run = 0;
+            // warm-up over the halo: same line as the block start unless a newline
+            // intervenes, and a newline resets the run anyway
+            {
+                const bool inseq = (lph & 3u) == 1u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    uint32_t b = ((j < 4 ? h0 : h1) >> (8 * (j & 3))) & 0xFFu;
+                    uint32_t c2 = ((b >> 1) ^ (b >> 2)) & 3u;
+                    uint32_t recon = (0x54474341u >> (c2 * 8u)) & 0xFFu;
+                    bool ok = inseq && (recon == (b & 0xDFu));
+                    fw = ((fw << 2) | c2) & MASK;
+                    run = ok ? run + 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t w = d[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t b = (w >> (8 * j)) & 0xFFu;
+                    uint32_t c2 = ((b >> 1) ^ (b >> 2)) & 3u;
+                    uint32_t recon = (0x54474341u >> (c2 * 8u)) & 0xFFu;
+                    bool ok = ((lph & 3u) == 1u) && (recon == (b & 0xDFu));
+                    fw = ((fw << 2) | c2) & MASK;
+                    run = ok ? run + 1u : 0u;
+                    if (run >= static_cast<uint32_t>(K)) {
+                        if (HPARTS == 1 || (fw >> PSHIFT) == hp) atomicAdd(&hist[fw & (BINS - 1u)], 1u);
+                    }
+                    lph += (b == 10u) ? 1u : 0u;
+                }
+            }
+            ph = (ph + total) & 3u;
+        }
+    }
+    if (hp == 0 && lane == 0) {
+        uint32_t idx = (s * parts + part) * kWaves + wave;
+        wavephase[idx] = empty ? 0x80u : (0x40u | ph_start | (ph << 2));
+    }
+
+    __syncthreads();
+    uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE + static_cast<uint64_t>(hp) * BINS;
+    if (atomic_flush) {
+        for (uint32_t i = tid; i < BINS; i += kCountThreads) {
+            uint32_t v = hist[i];
+            if (v) atomicAdd(&out[i], v);
+        }
+    } else {
+        for (uint32_t i = tid; i < BINS; i += kCountThreads) out[i] = hist[i];
+    }
+}
+
+// One thread per sample: the line phase each wave ended with must be the phase
+// the next wave recovered for itself, and the file must end after a quality line.
+__global__ void vk_check_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+                                const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+                                const uint32_t* __restrict__ wavephase, uint32_t* __restrict__ status) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsamples) return;
+    uint32_t st = 0;
+    const uint64_t len = lens[s];
+    if (len) {
+        const uint8_t* sbase = fastq + offs[s];
+        if (sbase[0] != '@') st |= VK_ST_BAD_START;
+        uint32_t prev = 0;  // phase at byte 0
+        const uint32_t* wp = wavephase + static_cast<uint64_t>(s) * parts * kWaves;
+        for (uint32_t i = 0; i < parts * kWaves; ++i) {
+            uint32_t v = wp[i];
+            if (v & 0x80u) continue;
+            if ((v & 3u) != prev) st |= VK_ST_BAD_PHASE;
+            prev = (v >> 2) & 3u;
+        }
+        uint32_t want = (sbase[len - 1] == '\n') ? 0u : 3u;
+        if (prev != want) st |= VK_ST_BAD_PHASE;
+    }
+    status[s] = st;
+}
+
+// --------------------------------------------------------------- K2 image ----
+
+constexpr int kImgThreads = 1024;
+constexpr uint32_t kTile = 16384;  // u32 elements sorted in LDS at a time (64 KiB)
+
+__device__ __forceinline__ uint32_t revcomp_code(uint32_t c, int k) {
+    // complement = 3 - b = ~b on 2 bits; reverse the k two-bit groups
+    uint32_t x = ~c;
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    x = (x >> 16) | (x << 16);
+    return x >> (32 - 2 * k);
+}
+
+__device__ __forceinline__ void cmpswap(uint32_t& a, uint32_t& b, bool asc) {
+    uint32_t lo = min(a, b), hi = max(a, b);
+    a = asc ? lo : hi;
+    b = asc ? hi : lo;
+}
+
+// All bitonic passes with stride < tile length, for merge size `size` and above
+// (up to `maxsize`), on a tile that sits in LDS.  gbase = global index of tile[0].
+__device__ void bitonic_tile(uint32_t* tile, uint32_t tlen, uint32_t gbase, uint32_t size_from,
+                             uint32_t size_to, bool only_tail) {
+    for (uint32_t size = size_from; size <= size_to; size <<= 1) {
+        uint32_t s0 = only_tail ? tlen >> 1 : size >> 1;
+        if (s0 > (tlen >> 1)) s0 = tlen >> 1;
+        for (uint32_t stride = s0; stride > 0; stride >>= 1) {
+            for (uint32_t i = threadIdx.x; i < (tlen >> 1); i += kImgThreads) {
+                uint32_t lo = ((i / stride) * 2u * stride) + (i % stride);
+                uint32_t hi = lo + stride;
+                bool asc = ((gbase + lo) & size) == 0u;
+                uint32_t a = tile[lo], b = tile[hi];
+                cmpswap(a, b, asc);
+                tile[lo] = a;
+                tile[hi] = b;
+            }
+            __syncthreads();
+        }
+        if (only_tail) break;
+    }
+}
+
+// One workgroup per sample.  scratch: [nsamples][2][npad] u32 (val, sorted).
+__global__ __launch_bounds__(kImgThreads) void vk_image_kernel(
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ pix, int k, uint32_t npix,
+    uint32_t npad, uint32_t* __restrict__ scratch, uint8_t* __restrict__ img) {
+    __shared__ uint32_t tile[kTile];
+    __shared__ unsigned long long bins[256];
+    const uint32_t s = blockIdx.x;
+    const uint32_t ncode = 1u << (2 * k);
+    const uint32_t* h = hist + static_cast<uint64_t>(s) * ncode;
+    uint32_t* val = scratch + static_cast<uint64_t>(s) * 2u * npad;
+    uint32_t* srt = val + npad;
+    const uint32_t tid = threadIdx.x;
+
+    for (uint32_t i = tid; i < npad; i += kImgThreads) val[i] = 0u;
+    __syncthreads();
+    // strand merge + scatter: every code writes tot+1 to its own pixel; s and rc(s)
+    // write the same value (to the same pixel for varKode, to two pixels for cgr)
+    for (uint32_t c = tid; c < ncode; c += kImgThreads) {
+        uint32_t r = revcomp_code(c, k);
+        uint32_t tot = (r == c) ? h[c] : h[c] + h[r];
+        val[pix[c]] = tot + 1u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < npad; i += kImgThreads) srt[i] = (i < npix) ? val[i] : 0xFFFFFFFFu;
+    __syncthreads();
+
+    const uint32_t tlen = npad < kTile ? npad : kTile;
+    const uint32_t ntiles = npad / tlen;
+    // phase 1: sort every tile completely (directions follow the global index)
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        for (uint32_t i = tid; i < tlen; i += kImgThreads) tile[i] = srt[t * tlen + i];
+        __syncthreads();
+        bitonic_tile(tile, tlen, t * tlen, 2u, tlen, false);
+        if (ntiles > 1) {
+            for (uint32_t i = tid; i < tlen; i += kImgThreads) srt[t * tlen + i] = tile[i];
+            __syncthreads();
+        }
+    }
+    // phase 2: merges wider than a tile: global passes, then the in-tile tail
+    for (uint32_t size = tlen << 1; size <= npad && ntiles > 1; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride >= tlen; stride >>= 1) {
+            for (uint32_t i = tid; i < (npad >> 1); i += kImgThreads) {
+                uint32_t lo = ((i / stride) * 2u * stride) + (i % stride);
+                uint32_t hi = lo + stride;
+                bool asc = (lo & size) == 0u;
+                uint32_t a = srt[lo], b = srt[hi];
+                cmpswap(a, b, asc);
+                srt[lo] = a;
+                srt[hi] = b;
+            }
+            __syncthreads();
+        }
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            for (uint32_t i = tid; i < tlen; i += kImgThreads) tile[i] = srt[t * tlen + i];
+            __syncthreads();
+            bitonic_tile(tile, tlen, t * tlen, size, size, true);
+            for (uint32_t i = tid; i < tlen; i += kImgThreads) srt[t * tlen + i] = tile[i];
+            __syncthreads();
+        }
+    }
+    const uint32_t* a = (ntiles > 1) ? srt : tile;
+
+    // 256 quantile bins, scaled by 256 (exact integers)
+    if (tid < 256) {
+        unsigned long long pos = static_cast<unsigned long long>(tid) * (npix - 1u);
+        uint32_t i = static_cast<uint32_t>(pos >> 8), g = static_cast<uint32_t>(pos & 255u);
+        uint32_t i1 = (i + 1u < npix) ? i + 1u : npix - 1u;
+        uint32_t ai = a[i], aj = a[i1];
+        bins[tid] = 256ull * ai + static_cast<unsigned long long>(aj - ai) * g;
+    }
+    __syncthreads();
+    uint8_t* out = img + static_cast<uint64_t>(s) * npix;
+    for (uint32_t p = tid; p < npix; p += kImgThreads) {
+        unsigned long long v = 256ull * val[p];
+        // upper_bound over the non-decreasing bins; bins[0] = 256*min <= v, so the
+        // answer lies in [1, 256]: 255 candidates to discard, 8 halvings
+        uint32_t lo = 1, hi = 256;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            uint32_t mid = (lo + hi) >> 1;
+            bool le = bins[mid] <= v;
+            lo = le ? mid + 1u : lo;
+            hi = le ? hi : mid;
+        }
+        out[p] = static_cast<uint8_t>(lo - 1u);
+    }
+}
+
+__global__ void vk_cgr_lut_kernel(int k, uint32_t* __restrict__ pix) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = 1u << (2 * k), side = 1u << k;
+    if (c >= n) return;
+    uint32_t x = 0, y = 0;
+    for (int i = 0; i < k; ++i) {
+        uint32_t b = (c >> (2 * (k - 1 - i))) & 3u;
+        x |= ((b >> 1) & 1u) << i;
+        y |= (((b >> 1) ^ b) & 1u) << i;
+    }
+    pix[c] = (side - 1u - y) * side + x;
+}
+
+// ------------------------------------------------------------------ synth ----
+
+__device__ __host__ inline uint64_t vk_mix(uint64_t seed, uint64_t s, uint64_t r, uint64_t w, uint64_t stream) {
+    uint64_t z = seed + s * 0x9E3779B97F4A7C15ull + r * 0xBF58476D1CE4E5B9ull + w * 0x94D049BB133111EBull +
+                 stream * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ inline uint8_t synth_base(uint64_t seed, uint32_t s, uint32_t r, uint32_t i, uint32_t readlen, int dist) {
+    const uint32_t w = i >> 4, j = i & 15u;
+    uint32_t b;
+    if (dist == 0) {
+        b = static_cast<uint32_t>(vk_mix(seed, s, r, w, 1) >> (2 * j)) & 3u;
+    } else {
+        // GC content gq/16 per sample, gq in 4..10; 4 random bits per base
+        uint32_t gq = 4u + static_cast<uint32_t>(vk_mix(seed, s, 0, 0, 3) % 7u);
+        uint32_t u = static_cast<uint32_t>(vk_mix(seed, s, r, w, 1) >> (4 * j)) & 15u;
+        uint32_t at = 16u - gq, a = (at + 1u) >> 1, cc = (gq + 1u) >> 1, g = gq >> 1;
+        b = u < a ? 0u : (u < a + cc ? 1u : (u < a + cc + g ? 2u : 3u));
+        // 1 read in 200 carries a homopolymer run of 20..60 bases
+        uint64_t hr = vk_mix(seed, s, r, 0, 4);
+        if (hr % 200u == 0u && readlen > 64u) {
+            uint32_t rl = 20u + static_cast<uint32_t>((hr >> 16) % 41u);
+            uint32_t st = static_cast<uint32_t>((hr >> 32) % (readlen - rl));
+            if (i >= st && i < st + rl) b = static_cast<uint32_t>(hr >> 8) & 3u;
+        }
+    }
+    uint64_t hn = vk_mix(seed, s, r, w, 2);
+    if (((hn >> 8) & 63u) == 0u && (hn & 15u) == j) return 'N';
+    return "ACGT"[b];
+}
+
+// one thread per 16 output bytes
+__global__ void vk_synth_kernel(uint8_t* __restrict__ out, uint32_t sample0, uint32_t nsamples, uint32_t reads,
+                                uint32_t readlen, uint64_t seed, int dist, uint64_t total16) {
+    const uint64_t rec = 2ull * readlen + 20ull;
+    for (uint64_t g = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; g < total16;
+         g += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        uint8_t bytes[16];
+        const uint64_t o0 = g * 16;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            uint64_t o = o0 + t;
+            uint64_t ridx = o / rec;
+            uint32_t off = static_cast<uint32_t>(o % rec);
+            uint32_t sl = static_cast<uint32_t>(ridx / reads);
+            uint32_t r = static_cast<uint32_t>(ridx % reads);
+            uint32_t s = sample0 + sl;
+            uint8_t ch;
+            if (sl >= nsamples) {
+                ch = 0;
+            } else if (off < 16) {
+                // "@sSSSSS.RRRRRRR\n"
+                if (off == 0) ch = '@';
+                else if (off == 1) ch = 's';
+                else if (off < 7) {
+                    uint32_t p10 = 1;
+                    for (uint32_t e = 0; e < 6 - off; ++e) p10 *= 10;
+                    ch = '0' + (s / p10) % 10;
+                } else if (off == 7) ch = '.';
+                else if (off < 15) {
+                    uint32_t p10 = 1;
+                    for (uint32_t e = 0; e < 14 - off; ++e) p10 *= 10;
+                    ch = '0' + (r / p10) % 10;
+                } else ch = '\n';
+            } else if (off < 16 + readlen) {
+                ch = synth_base(seed, s, r, off - 16, readlen, dist);
+            } else if (off == 16 + readlen) ch = '\n';
+            else if (off == 17 + readlen) ch = '+';
+            else if (off == 18 + readlen) ch = '\n';
+            else if (off < 19 + 2 * readlen) ch = 'I';
+            else ch = '\n';
+            bytes[t] = ch;
+        }
+        uint4 v;
+        memcpy(&v, bytes, 16);
+        *reinterpret_cast<uint4*>(out + o0) = v;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI ------
+
+struct vk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipError_t last = hipSuccess;
+    uint32_t* d_pix[10] = {};
+    uint32_t npix[10] = {};
+    // workspaces (grown on demand, never inside a timed launch after warm-up)
+    uint64_t* d_desc = nullptr;   // offsets | lengths
+    size_t desc_cap = 0;
+    uint64_t* h_desc = nullptr;   // pinned mirror of d_desc (descriptor cache)
+    size_t h_desc_cap = 0;
+    uint32_t desc_n = 0;
+    uint32_t* d_wavephase = nullptr;
+    size_t wavephase_cap = 0;
+    uint32_t* d_scratch = nullptr;
+    size_t scratch_cap = 0;
+    // host-call staging
+    uint8_t* d_stage = nullptr;
+    size_t stage_cap = 0;
+    uint32_t* d_hist1 = nullptr;
+    uint32_t* d_status1 = nullptr;
+    uint8_t* d_img1 = nullptr;
+    uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+};
+
+#define VK_HIP(ctx, call)                     \
+    do {                                      \
+        hipError_t e_ = (call);               \
+        if (e_ != hipSuccess) {               \
+            (ctx)->last = e_;                 \
+            return VK_EHIP;                   \
+        }                                     \
+    } while (0)
+
+namespace {
+
+int ensure(vk_ctx* ctx, void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return VK_OK;
+    if (*p) VK_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    size_t n = need + need / 4 + 256;
+    VK_HIP(ctx, hipMalloc(p, n));
+    *cap = n;
+    return VK_OK;
+}
+
+// Sample descriptors go through a pinned host mirror; an unchanged batch (the
+// steady state of a pipeline that recycles its buffers) is not uploaded again.
+int upload_desc(vk_ctx* ctx, const uint64_t* offsets, const uint64_t* lengths, uint32_t n) {
+    const size_t bytes = static_cast<size_t>(n) * sizeof(uint64_t);
+    if (ctx->desc_n == n && ctx->h_desc && memcmp(ctx->h_desc, offsets, bytes) == 0 &&
+        memcmp(ctx->h_desc + n, lengths, bytes) == 0)
+        return VK_OK;
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a previous upload may still read h_desc
+    if (ctx->h_desc_cap < 2 * bytes) {
+        if (ctx->h_desc) VK_HIP(ctx, hipHostFree(ctx->h_desc));
+        ctx->h_desc = nullptr;
+        ctx->h_desc_cap = 0;
+        VK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_desc), 2 * bytes + 4096, hipHostMallocDefault));
+        ctx->h_desc_cap = 2 * bytes + 4096;
+    }
+    memcpy(ctx->h_desc, offsets, bytes);
+    memcpy(ctx->h_desc + n, lengths, bytes);
+    ctx->desc_n = n;
+    VK_HIP(ctx, hipMemcpyAsync(ctx->d_desc, ctx->h_desc, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VK_OK;
+}
+
+uint32_t npad_of(uint32_t npix) {
+    uint32_t p = 1;
+    while (p < npix) p <<= 1;
+    return p;
+}
+
+template <int K, int LP>
+int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
+                 uint32_t nsamples, uint32_t parts, uint32_t* d_hist, int atomic_flush) {
+    constexpr uint32_t HP = 1u << LP;
+    uint32_t units = nsamples * parts;
+    uint32_t grid = ((units + 7u) / 8u) * 8u * HP;
+    ctx->last_grid = grid;
+    ctx->last_block = kCountThreads;
+    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece;
+    hipLaunchKernelGGL((vk_count_kernel<K, LP>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
+                       d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+uint32_t choose_parts(uint32_t nsamples, uint64_t maxlen) {
+    // enough workgroups to fill 256 CUs a few times over, but never ranges so
+    // small that the per-wave phase sync dominates
+    uint32_t parts = 1;
+    while (static_cast<uint64_t>(nsamples) * parts < 512 && (maxlen / (parts * 2)) >= (1u << 20)) parts *= 2;
+    return parts;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_abi_version(void) { return 1; }
+
+const char* vk_strerror(int status) {
+    switch (status) {
+        case VK_OK: return "ok";
+        case VK_EINVAL: return "invalid argument";
+        case VK_EHIP: return "HIP runtime error";
+        case VK_ENOMAP: return "no k-mer mapping installed for this k";
+        case VK_EFORMAT: return "inconsistent FASTQ framing";
+        case VK_ENOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* vk_last_hip_error(const vk_ctx* ctx) {
+    if (!ctx || ctx->last == hipSuccess) return "";
+    return hipGetErrorString(ctx->last);
+}
+
+int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
+    if (!out) return VK_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VK_EHIP;
+    vk_ctx* ctx = new (std::nothrow) vk_ctx();
+    if (!ctx) return VK_ENOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return VK_EHIP; }
+    if (!own_stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the device's default stream
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VK_EHIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return VK_OK;
+}
+
+void vk_ctx_destroy(vk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 10; ++k)
+        if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int vk_ctx_sync(vk_ctx* ctx) {
+    if (!ctx) return VK_EINVAL;
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_set_mapping(vk_ctx* ctx, int k, const uint32_t* pix, uint32_t npix) {
+    if (!ctx || k < 5 || k > 9) return VK_EINVAL;
+    const uint32_t ncode = 1u << (2 * k);
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    if (!pix) {
+        if (npix != ncode) return VK_EINVAL;
+    } else {
+        for (uint32_t c = 0; c < ncode; ++c)
+            if (pix[c] >= npix) return VK_EINVAL;
+    }
+    if (!ctx->d_pix[k]) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_pix[k]), ncode * sizeof(uint32_t)));
+    if (pix) {
+        VK_HIP(ctx, hipMemcpyAsync(ctx->d_pix[k], pix, ncode * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pix may be a temporary
+    } else {
+        hipLaunchKernelGGL(vk_cgr_lut_kernel, dim3((ncode + 255) / 256), dim3(256), 0, ctx->stream, k, ctx->d_pix[k]);
+        VK_HIP(ctx, hipGetLastError());
+    }
+    ctx->npix[k] = npix;
+    return VK_OK;
+}
+
+int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                    uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status) {
+    if (!ctx || !offsets || !lengths || !d_hist || !d_status || k < 5 || k > 9) return VK_EINVAL;
+    if (nsamples == 0) return VK_OK;
+    if (!d_fastq) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t maxlen = 0;
+    for (uint32_t i = 0; i < nsamples; ++i) {
+        if ((offsets[i] & 15u) != 0) return VK_EINVAL;
+        if (lengths[i] > maxlen) maxlen = lengths[i];
+    }
+    if ((reinterpret_cast<uintptr_t>(d_fastq) & 15u) != 0) return VK_EINVAL;
+    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
+    if (static_cast<uint64_t>(nsamples) * parts > (1u << 24)) return VK_EINVAL;
+
+    if (ctx->desc_cap < 2ull * nsamples * sizeof(uint64_t)) ctx->desc_n = 0;  // realloc drops the cached copy
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_desc), &ctx->desc_cap, 2ull * nsamples * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_wavephase), &ctx->wavephase_cap,
+                static_cast<size_t>(nsamples) * parts * kWaves * sizeof(uint32_t));
+    if (rc) return rc;
+    uint64_t* d_offs = ctx->d_desc;
+    uint64_t* d_lens = ctx->d_desc + nsamples;
+    rc = upload_desc(ctx, offsets, lengths, nsamples);
+    if (rc) return rc;
+    const size_t ncode = static_cast<size_t>(1) << (2 * k);
+    const int atomic_flush = parts > 1 ? 1 : 0;
+    if (atomic_flush)
+        VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * ncode * sizeof(uint32_t), ctx->stream));
+    const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
+    switch (k) {
+        case 5: rc = launch_count<5, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+        case 6: rc = launch_count<6, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+        case 7: rc = launch_count<7, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+        case 8: rc = launch_count<8, 2>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+        default: rc = launch_count<9, 4>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, d_offs, d_lens,
+                       nsamples, parts, ctx->d_wavephase, d_status);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int k, uint8_t* d_img) {
+    if (!ctx || !d_hist || !d_img || k < 5 || k > 9) return VK_EINVAL;
+    if (!ctx->d_pix[k]) return VK_ENOMAP;
+    if (nsamples == 0) return VK_OK;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = ctx->npix[k];
+    const uint32_t npad = npad_of(npix);
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_scratch), &ctx->scratch_cap,
+                    static_cast<size_t>(nsamples) * 2u * npad * sizeof(uint32_t));
+    if (rc) return rc;
+    hipLaunchKernelGGL(vk_image_kernel, dim3(nsamples), dim3(kImgThreads), 0, ctx->stream, d_hist, ctx->d_pix[k], k,
+                       npix, npad, ctx->d_scratch, d_img);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                             uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist,
+                             uint32_t* d_status, uint8_t* d_img) {
+    if (!ctx || k < 5 || k > 9) return VK_EINVAL;
+    if (!ctx->d_pix[k]) return VK_ENOMAP;
+    int rc = vk_count_device(ctx, d_fastq, offsets, lengths, nsamples, k, parts_per_sample, d_hist, d_status);
+    if (rc) return rc;
+    return vk_image_device(ctx, d_hist, nsamples, k, d_img);
+}
+
+int vk_count_host(vk_ctx* ctx, const uint8_t* fastq, size_t nbytes, int k, uint32_t* hist, uint32_t* status) {
+    if (!ctx || !hist || k < 5 || k > 9 || (nbytes && !fastq)) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ncode = static_cast<size_t>(1) << (2 * k);
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_stage), &ctx->stage_cap, nbytes + 64);
+    if (rc) return rc;
+    if (!ctx->d_hist1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_hist1), (1u << 18) * sizeof(uint32_t)));
+    if (!ctx->d_status1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_status1), 64));
+    if (nbytes)
+        VK_HIP(ctx, hipMemcpyAsync(ctx->d_stage, fastq, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t off = 0, len = nbytes;
+    rc = vk_count_device(ctx, ctx->d_stage, &off, &len, 1, k, 0, ctx->d_hist1, ctx->d_status1);
+    if (rc) return rc;
+    uint32_t st = 0;
+    VK_HIP(ctx, hipMemcpyAsync(hist, ctx->d_hist1, ncode * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (status) *status = st;
+    return st ? VK_EFORMAT : VK_OK;
+}
+
+int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img) {
+    if (!ctx || !hist || !img || k < 5 || k > 9) return VK_EINVAL;
+    if (!ctx->d_pix[k]) return VK_ENOMAP;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ncode = static_cast<size_t>(1) << (2 * k);
+    if (!ctx->d_hist1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_hist1), (1u << 18) * sizeof(uint32_t)));
+    if (!ctx->d_img1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_img1), 1u << 18));
+    VK_HIP(ctx, hipMemcpyAsync(ctx->d_hist1, hist, ncode * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    int rc = vk_image_device(ctx, ctx->d_hist1, 1, k, ctx->d_img1);
+    if (rc) return rc;
+    VK_HIP(ctx, hipMemcpyAsync(img, ctx->d_img1, ctx->npix[k], hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t nsamples, uint32_t reads,
+                          uint32_t readlen, uint64_t seed, int dist) {
+    if (!ctx || !d_out || readlen == 0 || reads == 0 || reads > 10000000u || (dist != 0 && dist != 1)) return VK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return VK_EINVAL;
+    if (nsamples == 0) return VK_OK;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t rec = 2ull * readlen + 20ull;
+    const uint64_t total = rec * reads * nsamples;
+    const uint64_t total16 = (total + 15) / 16;
+    uint64_t blocks = (total16 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(vk_synth_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, ctx->stream,
+                       static_cast<uint8_t*>(d_out), sample0, nsamples, reads, readlen, seed, dist, total16);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes) {
+    if (!ctx) return VK_EINVAL;
+    if (grid) *grid = ctx->last_grid;
+    if (block) *block = ctx->last_block;
+    if (lds_bytes) *lds_bytes = ctx->last_lds;
+    return VK_OK;
+}
+
+}  // extern "C"

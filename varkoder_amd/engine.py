@@ -1,0 +1,178 @@
+"""Device-resident batch interface to the HIP kernels (one process per GPU).
+
+PyTorch is used for device memory and the stream only; every computation is a call
+through the C ABI of include/vkimg.h.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .config import KMER_MAX, KMER_MIN
+from .mapping import pixel_lut, side
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ImageEngine:
+    """FASTQ (in HBM) -> forward k-mer histograms -> uint8 images, for one k and mapping.
+
+    Mirrors steps D+E of run_clean2img (varKoder/commands/image.py:1054-1127) for a
+    batch of samples that are already resident on the GPU.
+    """
+
+    def __init__(self, k=7, mapping="cgr", device=0, lut=None, npix=None):
+        if k not in range(KMER_MIN, KMER_MAX + 1):
+            raise ValueError("kmer size must be between 5 and 9")
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.VkError(_capi.VK_EHIP, "no GPU visible: the HIP path cannot run (no CPU fallback)")
+        self.k = k
+        self.mapping = mapping
+        self.device = torch.device("cuda", device)
+        self.L = _capi.lib()
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        ctx = C.c_void_p()
+        _capi.check(None, self.L.vk_ctx_create(device, C.c_void_p(self.stream.cuda_stream), 0, C.byref(ctx)),
+                    "vk_ctx_create")
+        self.ctx = ctx
+        if lut is None:
+            self.side = side(k, mapping)
+            self.npix = self.side * self.side
+            if mapping == "cgr":
+                st = self.L.vk_set_mapping(self.ctx, k, None, self.npix)
+            else:
+                lut = np.ascontiguousarray(pixel_lut(k, mapping), dtype=np.uint32)
+                st = self.L.vk_set_mapping(self.ctx, k, lut.ctypes.data_as(C.POINTER(C.c_uint32)), self.npix)
+        else:
+            lut = np.ascontiguousarray(lut, dtype=np.uint32)
+            self.npix = int(npix)
+            self.side = int(round(self.npix ** 0.5))
+            st = self.L.vk_set_mapping(self.ctx, k, lut.ctypes.data_as(C.POINTER(C.c_uint32)), self.npix)
+        _capi.check(self.ctx, st, "vk_set_mapping")
+        self.ncode = 4 ** k
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.vk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------
+    @staticmethod
+    def _desc(offsets, lengths):
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        if offs.shape != lens.shape or offs.ndim != 1:
+            raise ValueError("offsets and lengths must be 1-D and of equal length")
+        return offs, lens
+
+    def _ptr(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def upload(self, samples):
+        """Pack host FASTQ byte strings into one device buffer at 16-byte aligned
+        offsets; returns (tensor, offsets, lengths)."""
+        torch = _torch()
+        lens = np.array([len(s) for s in samples], dtype=np.uint64)
+        offs = np.zeros(len(samples), dtype=np.uint64)
+        pos = 0
+        for i, n in enumerate(lens):
+            offs[i] = pos
+            pos += (int(n) + 15) // 16 * 16
+        host = np.zeros(pos + 16, dtype=np.uint8)
+        for s, o, n in zip(samples, offs, lens):
+            host[int(o):int(o) + int(n)] = np.frombuffer(bytes(s), dtype=np.uint8) if not isinstance(s, np.ndarray) else s
+        dev = torch.from_numpy(host).to(self.device)
+        return dev, offs, lens
+
+    # -- stages ----------------------------------------------------------------
+    def count(self, fastq, offsets, lengths, parts=0, hist=None, status=None):
+        """K1 (+check): forward-strand histograms int32/uint32 [n, 4^k] and status [n]."""
+        torch = _torch()
+        offs, lens = self._desc(offsets, lengths)
+        n = len(offs)
+        if hist is None:
+            hist = torch.empty((n, self.ncode), dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        st = self.L.vk_count_device(self.ctx, self._ptr(fastq), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                    lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, self.k, parts,
+                                    self._ptr(hist), self._ptr(status))
+        _capi.check(self.ctx, st, "vk_count_device")
+        return hist, status
+
+    def images(self, hist, img=None):
+        """K2: uint8 images [n, side, side] from histograms [n, 4^k]."""
+        torch = _torch()
+        n = hist.shape[0]
+        if img is None:
+            img = torch.empty((n, self.side, self.side), dtype=torch.uint8, device=self.device)
+        st = self.L.vk_image_device(self.ctx, self._ptr(hist), n, self.k, self._ptr(img))
+        _capi.check(self.ctx, st, "vk_image_device")
+        return img
+
+    def fastq_to_images(self, fastq, offsets, lengths, parts=0, hist=None, status=None, img=None):
+        torch = _torch()
+        offs, lens = self._desc(offsets, lengths)
+        n = len(offs)
+        if hist is None:
+            hist = torch.empty((n, self.ncode), dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if img is None:
+            img = torch.empty((n, self.side, self.side), dtype=torch.uint8, device=self.device)
+        st = self.L.vk_fastq_to_image_device(self.ctx, self._ptr(fastq),
+                                             offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             lens.ctypes.data_as(C.POINTER(C.c_uint64)), n, self.k, parts,
+                                             self._ptr(hist), self._ptr(status), self._ptr(img))
+        _capi.check(self.ctx, st, "vk_fastq_to_image_device")
+        return img, hist, status
+
+    def synth(self, sample0, nsamples, reads, readlen=150, seed=20250824, dist=0, out=None):
+        """Synthetic FASTQ for samples sample0..sample0+nsamples-1, generated in HBM."""
+        torch = _torch()
+        rec = 2 * readlen + 20
+        total = rec * reads * nsamples
+        if out is None:
+            out = torch.empty(((total + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=self.device)
+        st = self.L.vk_synth_fastq_device(self.ctx, self._ptr(out), sample0, nsamples, reads, readlen,
+                                          C.c_uint64(seed), dist)
+        _capi.check(self.ctx, st, "vk_synth_fastq_device")
+        offs = np.arange(nsamples, dtype=np.uint64) * np.uint64(rec * reads)
+        lens = np.full(nsamples, rec * reads, dtype=np.uint64)
+        return out, offs, lens
+
+    def last_count_launch(self):
+        g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.L.vk_last_count_launch(self.ctx, C.byref(g), C.byref(b), C.byref(l))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    # -- host conveniences -------------------------------------------------------
+    def count_host(self, data):
+        """One host FASTQ byte string -> (hist uint32[4^k], status bits)."""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data)
+        hist = np.empty(self.ncode, dtype=np.uint32)
+        stw = C.c_uint32(0)
+        st = self.L.vk_count_host(self.ctx, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, self.k,
+                                  hist.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(stw))
+        if st not in (_capi.VK_OK, _capi.VK_EFORMAT):
+            _capi.check(self.ctx, st, "vk_count_host")
+        return hist, stw.value
+
+    def image_host(self, hist):
+        hist = np.ascontiguousarray(hist, dtype=np.uint32)
+        img = np.empty(self.npix, dtype=np.uint8)
+        st = self.L.vk_image_host(self.ctx, hist.ctypes.data_as(C.POINTER(C.c_uint32)), self.k,
+                                  img.ctypes.data_as(C.POINTER(C.c_uint8)))
+        _capi.check(self.ctx, st, "vk_image_host")
+        return img.reshape(self.side, self.side)

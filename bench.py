@@ -7,7 +7,7 @@ k=7 varKode (91x91), 1x MI355X.  One "step" = one pass of the whole hot path
 (FASTQ text resident in HBM -> k-mer histograms -> uint8 images) over that batch.
 
 320 GB of distinct text does not fit one GPU, so -- as SURVEY.md 8d prescribes -- a pool
-of `--pool` distinct samples (default 64 = 20.5 GB) is generated on the device and the
+of `--pool` distinct samples (default 256 = 82 GB, one per concurrently resident workgroup) is generated on the device and the
 batch of 1000 cycles through it; every batch entry still gets its own histogram and
 image.  Generation is outside the timed region.
 
@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--readlen", type=int, default=150)
     ap.add_argument("--k", type=int, default=7)
     ap.add_argument("--mapping", default="varKode")
-    ap.add_argument("--pool", type=int, default=64, help="distinct samples resident in HBM")
+    ap.add_argument("--pool", type=int, default=256, help="distinct samples resident in HBM")
     ap.add_argument("--dist", type=int, default=0, help="0 uniform, 1 GC-skew + homopolymers")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per sample (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -20,7 +20,8 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INC, "vkimg.h")))
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INC, "vkimg.h")),
+                 os.path.getmtime(os.path.join(HERE, "csrc", "vk_lane.h")))
     return os.path.getmtime(OUT) < newest
 
 

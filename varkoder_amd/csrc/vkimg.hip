@@ -32,6 +32,7 @@
 #include <new>
 
 #include "vkimg.h"
+#include "vk_lane.h"
 
 namespace {
 
@@ -122,6 +123,22 @@ __device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, 
 
 // --------------------------------------------------------------- K1 count ----
 
+// reverse the order of the K two-bit groups of a code (no complement)
+__device__ __forceinline__ uint32_t pair_reverse(uint32_t c, int k) {
+    uint32_t x = c;
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    x = (x >> 16) | (x << 16);
+    return x >> (32 - 2 * k);
+}
+
+// 16 bytes at signed sample offset `off`: zero before the sample and at or beyond `lim`.
+__device__ __forceinline__ uint4 load_granule_s(const uint8_t* sbase, long long off, uint64_t lim) {
+    if (off < 0) return zero4();
+    return load_granule(sbase, static_cast<uint64_t>(off), lim);
+}
+
 template <int K, int LOG_PARTS>
 __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
@@ -130,12 +147,14 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr uint32_t HPARTS = 1u << LOG_PARTS;
     constexpr uint32_t BINS = NCODE >> LOG_PARTS;
-    constexpr uint32_t MASK = NCODE - 1u;
     constexpr uint32_t PSHIFT = 2 * K - LOG_PARTS;
     static_assert(BINS <= kMaxBins, "LDS histogram too large");
 
+    // The LDS histogram is indexed by the RAW packed field (first base least
+    // significant, see vk_lane.h); the flush un-reverses to the ABI's code order.
     __shared__ uint32_t hist[BINS];
     __shared__ uint4 stage[kWaves][kPiece / 16];
+    __shared__ uint4 below[66];  // below[q] = bits [0, 2q) of a 128-bit string
 
     // block -> (unit = (sample, part), histogram part); the HPARTS siblings of a
     // unit get block ids that differ by multiples of 8, i.e. share an XCD's L2.
@@ -153,6 +172,10 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const int wave = tid >> 6;
 
     for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
+    if (tid < 66) {
+        vkl::Mask128 m = vkl::ones_below(static_cast<uint32_t>(tid));
+        below[tid] = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
+    }
     __syncthreads();
 
     const uint8_t* sbase = fastq + offs[s];
@@ -167,29 +190,39 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const uint64_t w0 = blk0 << 6;
     const uint64_t w1 = empty ? w0 : umin64(blk1 << 6, len);
 
-    uint32_t ph_start = 0, ph = 0;
+    uint32_t ph_start = 0, ph_end = 0;
     if (!empty) {
         uint64_t* slot = reinterpret_cast<uint64_t*>(&stage[wave][0]);
-        if (w0 != 0) ph = sync_phase(sbase, w0, len, slot, lane);
-        ph_start = ph;
+        const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, slot, lane) : 0u;
+        ph_start = ph0;
 
-        // halo: the 8 bytes before the range (zeros at the sample start)
-        uint32_t carry0 = 0, carry1 = 0;
-        if (w0 != 0) {
-            uint2 h = *reinterpret_cast<const uint2*>(sbase + w0 - 8);
-            carry0 = h.x;
-            carry1 = h.y;
-        }
-
-        const uint64_t npieces = (w1 - w0 + kPiece - 1) / kPiece;
+        // Pieces start one 64-byte block BEFORE the range: lane 0 of piece 0 (the
+        // "pre-block") only supplies the k-1 bases of context and its windows are
+        // not counted.  From then on lane 0 takes its context from lane 63 of the
+        // previous piece.
+        const long long o0 = static_cast<long long>(w0) - 64;
+        const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
         uint4 r0, r1, r2, r3;
         {
-            uint64_t p = w0 + static_cast<uint64_t>(lane) * 16;
-            r0 = load_granule(sbase, p, w1);
-            r1 = load_granule(sbase, p + 1024, w1);
-            r2 = load_granule(sbase, p + 2048, w1);
-            r3 = load_granule(sbase, p + 3072, w1);
+            long long p = o0 + static_cast<long long>(lane) * 16;
+            r0 = load_granule_s(sbase, p, w1);
+            r1 = load_granule_s(sbase, p + 1024, w1);
+            r2 = load_granule_s(sbase, p + 2048, w1);
+            r3 = load_granule_s(sbase, p + 3072, w1);
         }
+        uint32_t carry_c = 0u, carry_bad = 0x55555555u;
+        uint32_t pph = 0;  // line phase at the start of the current piece
+        auto tbl = [&](uint32_t q) {
+            uint4 v = below[q];
+            vkl::Mask128 m;
+            m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+            return m;
+        };
+        auto emit = [&](uint32_t a4) {
+            // a4 = raw field << 2 = byte offset into the raw-indexed histogram
+            if (HPARTS == 1 || (a4 >> (PSHIFT + 2)) == hp)
+                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + (a4 & ((BINS - 1u) << 2))), 1u);
+        };
         for (uint64_t it = 0; it < npieces; ++it) {
             // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
             uint4* st = &stage[wave][0];
@@ -201,20 +234,19 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             wave_lds_fence();
             uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
             wave_lds_fence();
-            if (it + 1 < npieces) {  // prefetch the next piece under the walk
-                uint64_t p = w0 + (it + 1) * kPiece + static_cast<uint64_t>(lane) * 16;
-                r0 = load_granule(sbase, p, w1);
-                r1 = load_granule(sbase, p + 1024, w1);
-                r2 = load_granule(sbase, p + 2048, w1);
-                r3 = load_granule(sbase, p + 3072, w1);
+            if (it + 1 < npieces) {  // prefetch the next piece under the SWAR work
+                long long p = o0 + static_cast<long long>(it + 1) * kPiece + static_cast<long long>(lane) * 16;
+                r0 = load_granule_s(sbase, p, w1);
+                r1 = load_granule_s(sbase, p + 1024, w1);
+                r2 = load_granule_s(sbase, p + 2048, w1);
+                r3 = load_granule_s(sbase, p + 3072, w1);
             }
-            uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                              q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            vkl::LaneBits lb;
+            const uint32_t c = vkl::classify(d, lb);
 
-            // newline prefix -> line phase at the start of this lane's 64 bytes
-            uint32_t c = 0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) c += __popc(nl_flags(d[q]));
+            // newline prefix over the wave -> line phase at the start of each lane's block
             uint32_t incl = c;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
@@ -222,63 +254,42 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
                 if (lane >= dd) incl += t;
             }
             const uint32_t total = __shfl(incl, 63);
-            uint32_t lph = ph + incl - c;  // only the low 2 bits matter
+            if (it == 0) pph = ph0 - __shfl(c, 0);  // the pre-block's newlines precede w0
+            const uint32_t lph = (pph + incl - c) & 3u;
 
-            // the 8 bytes before this lane's block
-            uint32_t h0 = __shfl_up(d[14], 1), h1 = __shfl_up(d[15], 1);
-            if (lane == 0) { h0 = carry0; h1 = carry1; }
-            carry0 = __shfl(d[14], 63);
-            carry1 = __shfl(d[15], 63);
+            vkl::Mask128 seq;
+            if (__any(c > 3u)) seq = vkl::seq_mask_general(lb.NL, lph);
+            else seq = vkl::seq_mask_fast(lb.NL, lph, tbl);
+            uint32_t bad[4], ok[4];
+            vkl::bad_mask(lb, seq, bad);
 
-            uint32_t fw = 0, run = 0;
-            // warm-up over the halo: same line as the block start unless a newline
-            // intervenes, and a newline resets the run anyway
-            {
-                const bool inseq = (lph & 3u) == 1u;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    uint32_t b = ((j < 4 ? h0 : h1) >> (8 * (j & 3))) & 0xFFu;
-                    uint32_t c2 = ((b >> 1) ^ (b >> 2)) & 3u;
-                    uint32_t recon = (0x54474341u >> (c2 * 8u)) & 0xFFu;
-                    bool ok = inseq && (recon == (b & 0xDFu));
-                    fw = ((fw << 2) | c2) & MASK;
-                    run = ok ? run + 1u : 0u;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const uint32_t w = d[q];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t b = (w >> (8 * j)) & 0xFFu;
-                    uint32_t c2 = ((b >> 1) ^ (b >> 2)) & 3u;
-                    uint32_t recon = (0x54474341u >> (c2 * 8u)) & 0xFFu;
-                    bool ok = ((lph & 3u) == 1u) && (recon == (b & 0xDFu));
-                    fw = ((fw << 2) | c2) & MASK;
-                    run = ok ? run + 1u : 0u;
-                    if (run >= static_cast<uint32_t>(K)) {
-                        if (HPARTS == 1 || (fw >> PSHIFT) == hp) atomicAdd(&hist[fw & (BINS - 1u)], 1u);
-                    }
-                    lph += (b == 10u) ? 1u : 0u;
-                }
-            }
-            ph = (ph + total) & 3u;
+            uint32_t badh = __shfl_up(bad[3], 1), ch = __shfl_up(lb.C[3], 1);
+            if (lane == 0) { badh = carry_bad; ch = carry_c; }
+            carry_bad = __shfl(bad[3], 63);
+            carry_c = __shfl(lb.C[3], 63);
+
+            vkl::ok_mask<K>(badh, bad, ok);
+            if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+            vkl::windows<K>(ch, lb.C, ok, emit);
+            pph += total;
         }
+        ph_end = pph & 3u;
     }
     if (hp == 0 && lane == 0) {
         uint32_t idx = (s * parts + part) * kWaves + wave;
-        wavephase[idx] = empty ? 0x80u : (0x40u | ph_start | (ph << 2));
+        wavephase[idx] = empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
     }
 
     __syncthreads();
-    uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE + static_cast<uint64_t>(hp) * BINS;
-    if (atomic_flush) {
-        for (uint32_t i = tid; i < BINS; i += kCountThreads) {
-            uint32_t v = hist[i];
-            if (v) atomicAdd(&out[i], v);
+    uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
+    for (uint32_t i = tid; i < BINS; i += kCountThreads) {
+        const uint32_t v = hist[i];
+        const uint32_t code = pair_reverse((hp << PSHIFT) | i, K);  // ABI order: first base most significant
+        if (atomic_flush) {
+            if (v) atomicAdd(&out[code], v);
+        } else {
+            out[code] = v;
         }
-    } else {
-        for (uint32_t i = tid; i < BINS; i += kCountThreads) out[i] = hist[i];
     }
 }
 
@@ -623,7 +634,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     uint32_t grid = ((units + 7u) / 8u) * 8u * HP;
     ctx->last_grid = grid;
     ctx->last_block = kCountThreads;
-    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece;
+    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece + 66 * 16;
     hipLaunchKernelGGL((vk_count_kernel<K, LP>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
                        d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
     VK_HIP(ctx, hipGetLastError());

@@ -1,0 +1,117 @@
+// lane_emul.cpp -- CPU emulation of vk_count_kernel's wavefront algorithm (test only).
+//
+// Re-uses the product's per-lane SWAR routines (varkoder_amd/csrc/vk_lane.h, host
+// build) and re-states the surrounding wave logic of csrc/vkimg.hip sequentially:
+// byte-range split over parts x 16 waves, local line-phase recovery, pieces that start
+// one block before the range, newline prefix over the 64 lanes, halo carried from lane
+// to lane.  Lets the CPU test-suite check the algorithm against the oracle without a GPU.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "vk_lane.h"
+
+namespace {
+
+constexpr int kWaves = 16;
+constexpr int kPiece = 4096;
+
+uint32_t pair_reverse(uint32_t c, int k) {
+    uint32_t r = 0;
+    for (int i = 0; i < k; ++i) { r = (r << 2) | (c & 3u); c >>= 2; }
+    return r;
+}
+
+// csrc/vkimg.hip sync_phase(), scalar
+uint32_t sync_phase(const uint8_t* s, uint64_t w0, uint64_t len) {
+    uint64_t nl[6];
+    uint32_t n = 0;
+    for (uint64_t p = w0; p < len && n < 6; ++p)
+        if (s[p] == '\n') nl[n++] = p;
+    for (uint32_t i = 0; i + 2 < n && i < 4; ++i) {
+        uint64_t li = nl[i] + 1, lj = nl[i + 2] + 1;
+        if (lj < len && s[li] == '@' && s[lj] == '+') return (3u - i) & 3u;
+    }
+    uint32_t cnt = 0;
+    for (uint64_t p = 0; p < w0; ++p) cnt += s[p] == '\n';
+    return cnt & 3u;
+}
+
+template <int K>
+int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status) {
+    const uint32_t ncode = 1u << (2 * K);
+    std::vector<uint32_t> raw(ncode, 0u);
+    const uint64_t nblk = (len + 63) >> 6;
+    const uint64_t bwg = (nblk + parts - 1) / parts;
+    const uint64_t bw = (bwg + kWaves - 1) / kWaves;
+    uint32_t st = 0, prev_end = 0;
+    if (len && s[0] != '@') st |= 1u;
+    for (uint32_t part = 0; part < parts; ++part)
+        for (int wave = 0; wave < kWaves; ++wave) {
+            uint64_t blk0 = (uint64_t)part * bwg + (uint64_t)wave * bw;
+            uint64_t blk1 = (uint64_t)part * bwg + std::min<uint64_t>((uint64_t)(wave + 1) * bw, bwg);
+            if (blk1 > nblk) blk1 = nblk;
+            if (blk0 >= blk1) continue;
+            const uint64_t w0 = blk0 << 6, w1 = std::min<uint64_t>(blk1 << 6, len);
+            const uint32_t ph0 = w0 ? sync_phase(s, w0, len) : 0u;
+            if (ph0 != prev_end) st |= 2u;
+            const long long o0 = (long long)w0 - 64;
+            const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
+            uint32_t carry_c = 0, carry_bad = 0x55555555u, pph = 0;
+            for (uint64_t it = 0; it < npieces; ++it) {
+                uint8_t piece[kPiece];
+                for (int i = 0; i < kPiece; ++i) {
+                    long long off = o0 + (long long)it * kPiece + i;
+                    piece[i] = (off >= 0 && (uint64_t)off < w1) ? s[off] : 0;
+                }
+                vkl::LaneBits lb[64];
+                uint32_t c[64], total = 0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    uint32_t d[16];
+                    memcpy(d, piece + 64 * lane, 64);
+                    c[lane] = vkl::classify(d, lb[lane]);
+                    total += c[lane];
+                }
+                if (it == 0) pph = ph0 - c[0];
+                bool any_gt3 = false;
+                for (int lane = 0; lane < 64; ++lane) any_gt3 |= c[lane] > 3;
+                uint32_t excl = 0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const uint32_t lph = (pph + excl) & 3u;
+                    excl += c[lane];
+                    vkl::Mask128 seq = any_gt3 ? vkl::seq_mask_general(lb[lane].NL, lph)
+                                               : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below);
+                    uint32_t bad[4], ok[4];
+                    vkl::bad_mask(lb[lane], seq, bad);
+                    const uint32_t badh = carry_bad, ch = carry_c;  // lane-1's (or last piece's lane 63)
+                    carry_bad = bad[3];
+                    carry_c = lb[lane].C[3];
+                    vkl::ok_mask<K>(badh, bad, ok);
+                    if (it == 0 && lane == 0) ok[0] = ok[1] = ok[2] = ok[3] = 0;
+                    vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; });
+                }
+                pph += total;
+            }
+            prev_end = pph & 3u;
+        }
+    if (len) {
+        uint32_t want = s[len - 1] == '\n' ? 0u : 3u;
+        if (prev_end != want) st |= 2u;
+    }
+    for (uint32_t i = 0; i < ncode; ++i) hist[pair_reverse(i, K)] += raw[i];
+    *status = st;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int emul_count(const uint8_t* s, uint64_t len, int k, uint32_t parts, uint32_t* hist, uint32_t* status) {
+    switch (k) {
+        case 5: return count_impl<5>(s, len, parts, hist, status);
+        case 6: return count_impl<6>(s, len, parts, hist, status);
+        case 7: return count_impl<7>(s, len, parts, hist, status);
+        case 8: return count_impl<8>(s, len, parts, hist, status);
+        case 9: return count_impl<9>(s, len, parts, hist, status);
+        default: return 1;
+    }
+}

@@ -1,0 +1,99 @@
+"""The drop-in boundary on the GPU: count_kmers()/make_image() with the reference's
+signatures, file naming, PNG metadata and error behaviour (commands/image.py:727-936)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from varkoder_amd import image, synth
+from varkoder_amd.mapping import get_kmer_mapping, pixel_lut, side
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_fastq(path, sample, reads, gz=False):
+    data = synth.sample_fastq(sample, reads, 150, dist=1).tobytes()
+    if gz:
+        import gzip
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        path.write_bytes(data)
+    return data
+
+
+@pytest.mark.parametrize("k,mapping,gz", [(7, "cgr", True), (7, "varKode", False), (5, "cgr", False)])
+def test_count_then_image_like_run_clean2img(tmp_path, k, mapping, gz):
+    from PIL import Image
+    fq = tmp_path / ("SRR1@00000500K.fq.gz" if gz else "SRR1@00000500K.fq")
+    data = _write_fastq(fq, 9, 3500, gz)
+    counts_d, images_d = tmp_path / f"{k}mer_counts", tmp_path / "images"
+
+    st = image.count_kmers(fq, counts_d, threads=1, k=k)
+    assert list(st.keys()) == [f"{k}mer_counting_time"]
+    h5 = counts_d / f"SRR1@00000500K+k{k}.fq.h5"
+    assert h5.is_file()
+    assert image.count_kmers(fq, counts_d, k=k) == {}            # exists, no overwrite -> skipped
+
+    kk, hist = image.read_counts(h5)
+    want_h = oracle.count_fastq(data, k)[0]
+    assert kk == k and np.array_equal(hist, want_h)
+
+    kmap = get_kmer_mapping(k, mapping)
+    st = image.make_image(h5, images_d, kmap, labels=["genus:Bembidion", "sp:x"], base_sd=0.0123,
+                          mapping_code=mapping)
+    assert list(st.keys()) == [f"k{k}_img_time"]
+    png = images_d / f"SRR1@00000500K+{mapping}+k{k}.png"
+    assert png.is_file()
+    assert image.make_image(h5, images_d, kmap, mapping_code=mapping) == {}   # skipped
+
+    im = Image.open(png)
+    assert im.mode == "L"
+    n = side(k, mapping)
+    want_i = oracle.image(oracle.strand_merge(want_h, k), k, pixel_lut(k, mapping), n * n).reshape(n, n)
+    assert np.array_equal(np.array(im), want_i)
+    info = {a: b for a, b in im.info.items() if a.startswith("varkoder")}
+    assert list(info.keys()) == ["varkoderKeywords", "varkoderBaseFreqSd", "varkoderLowQualityFlag",
+                                 "varkoderMapping"]
+    assert info == {"varkoderKeywords": "genus:Bembidion;sp:x", "varkoderBaseFreqSd": "0.0123",
+                    "varkoderLowQualityFlag": "True", "varkoderMapping": mapping}
+
+
+def test_png_metadata_equals_reference_cases(tmp_path, manifest):
+    """Text chunks, file name and stats key as the reference's make_image wrote them
+    (tests/golden/manifest.json, png_metadata_cases; produced by oracle/gen_golden.py)."""
+    from PIL import Image
+    import vectors
+    kmap = get_kmer_mapping(5, "cgr")
+    for case in manifest["png_metadata_cases"]:
+        h5 = tmp_path / f"{case['sample']}@00010000K+k5.fq.h5"
+        image.write_counts(h5, 5, vectors.fwd_hist(5, "heavy"))
+        st = image.make_image(h5, tmp_path / "out", kmap, overwrite=True, labels=case["labels"],
+                              base_sd=case["base_sd"], mapping_code="cgr")
+        assert list(st.keys()) == case["stats_keys"]
+        png = tmp_path / "out" / case["filename"]
+        assert png.is_file()
+        im = Image.open(png)
+        info = {a: b for a, b in im.info.items() if a.startswith("varkoder")}
+        assert info == case["info"]
+        got = hashlib.sha256(np.array(im).astype(np.uint8).tobytes()).hexdigest()
+        assert got == manifest["image_cases"]["k5_cgr_heavy"]["sha256"]
+
+
+def test_subfolder_levels_and_errors(tmp_path):
+    import pandas as pd
+    kmap = get_kmer_mapping(5, "varKode")
+    h5 = tmp_path / "S@00000010K+k5.fq.h5"
+    image.write_counts(h5, 5, np.ones(4 ** 5, dtype=np.uint32))
+    image.make_image(h5, tmp_path / "img", kmap, subfolder_levels=2, mapping_code="varKode")
+    name = "S@00000010K+varKode+k5.png"
+    hsh = list(hashlib.md5(name.encode("UTF-8")).hexdigest())
+    assert (tmp_path / "img" / hsh.pop() / hsh.pop() / name).is_file()      # image.py:850-854
+    image.write_counts(h5, 5, np.zeros(4 ** 5, dtype=np.uint32))
+    with pytest.raises(pd.errors.EmptyDataError):                            # empty dsk2ascii dump
+        image.make_image(h5, tmp_path / "img2", kmap, mapping_code="varKode")
+    bad = tmp_path / "B@00000010K.fq"
+    bad.write_bytes(b"@r\nACGTACGTAC\n+\n")                                  # truncated record
+    with pytest.raises(RuntimeError):
+        image.count_kmers(bad, tmp_path / "c", k=5)

@@ -1,0 +1,65 @@
+"""CPU emulation of the count kernel's wavefront algorithm (tests/emul/lane_emul.cpp, built
+around the product's own csrc/vk_lane.h) against the oracle.  No GPU needed."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from fastq_cases import edge_cases
+from oracle import oracle
+from varkoder_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(HERE, "emul", "lane_emul.cpp")
+    so = os.path.join(HERE, "emul", "liblane_emul.so")
+    hdr = os.path.join(ROOT, "varkoder_amd", "csrc", "vk_lane.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I",
+                               os.path.join(ROOT, "varkoder_amd", "csrc"), src, "-o", so])
+    L = C.CDLL(so)
+    L.emul_count.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+
+    def run(fq, k, parts):
+        buf = np.frombuffer(bytes(fq), dtype=np.uint8) if not isinstance(fq, np.ndarray) else fq
+        pad = np.zeros(buf.size + 64, dtype=np.uint8)
+        pad[:buf.size] = buf
+        hist = np.zeros(4 ** k, dtype=np.uint32)
+        st = C.c_uint32(0)
+        assert L.emul_count(pad.ctypes.data, buf.size, k, parts, hist.ctypes.data, C.byref(st)) == 0
+        return hist, st.value
+    return run
+
+
+@pytest.mark.parametrize("k", (5, 6, 7, 8, 9))
+def test_emulated_wave_equals_oracle_on_edge_cases(emul, k):
+    for name, fq in edge_cases().items():
+        want, nwin, st = oracle.count_fastq(fq, k)
+        for parts in (1, 3):
+            got, status = emul(fq, k, parts)
+            assert status == 0 and st == 0, (name, parts)
+            assert np.array_equal(got, want), (name, parts)
+
+
+@pytest.mark.parametrize("dist", (0, 1))
+def test_emulated_wave_equals_oracle_on_synthetic(emul, dist):
+    fq = synth.sample_fastq(21, 4000, 150, dist=dist)
+    for k in (5, 7, 9):
+        want = oracle.count_fastq(fq, k)[0]
+        for parts in (1, 2, 7):
+            got, status = emul(fq, k, parts)
+            assert status == 0
+            assert np.array_equal(got, want), (k, parts)
+
+
+def test_emulated_wave_flags_bad_framing(emul):
+    good = synth.sample_fastq(1, 50, 150).tobytes()
+    assert emul(good, 7, 1)[1] == 0
+    assert emul(good[1:], 7, 1)[1] & 1
+    assert emul(good[:-200], 7, 2)[1] & 2

@@ -97,3 +97,33 @@ def test_subfolder_levels_and_errors(tmp_path):
     bad.write_bytes(b"@r\nACGTACGTAC\n+\n")                                  # truncated record
     with pytest.raises(RuntimeError):
         image.count_kmers(bad, tmp_path / "c", k=5)
+
+
+def test_batched_pipeline_writes_reference_named_pngs(tmp_path):
+    """pipeline.fastqs_to_images: many split FASTQs per launch, PNGs + stats keys as steps D+E
+    of run_clean2img (image.py:1054-1127); pixels equal the oracle's."""
+    from PIL import Image
+    from varkoder_amd import pipeline
+    files, datas = [], {}
+    for s, reads in enumerate((1200, 800, 2500, 400)):
+        f = tmp_path / f"samp{s}@{reads * 150 // 1000:08d}K.fq"
+        datas[f.name] = _write_fastq(f, 40 + s, reads)
+        files.append(f)
+    bad = tmp_path / "broken@00000001K.fq"
+    bad.write_bytes(b"@r\nACGTACGTACGT\n+\n")
+    files.append(bad)
+    stats = pipeline.fastqs_to_images(files, tmp_path / "images", k=7, mapping_code="varKode",
+                                      labels={"samp1": ["t:a", "t:b"]}, batch_bytes=600000)
+    assert stats["broken@00000001K"] == {"failed_step": "image"}
+    n = side(7, "varKode")
+    for f in files[:-1]:
+        key = f.name[:-3]
+        assert list(stats[key].keys()) == ["7mer_counting_time", "k7_img_time"]
+        png = tmp_path / "images" / f"{key}+varKode+k7.png"
+        im = Image.open(png)
+        want, _, st = oracle.fastq_to_image(datas[f.name], 7, pixel_lut(7, "varKode"), n * n)
+        assert st == 0 and np.array_equal(np.array(im).ravel(), want)
+        assert im.info["varkoderKeywords"] == ("t:a;t:b" if key.startswith("samp1") else "")
+    # a second run skips what exists (checkpoint/resume by file existence, image.py:857-859)
+    again = pipeline.fastqs_to_images(files[:-1], tmp_path / "images", k=7, mapping_code="varKode")
+    assert again == {}

@@ -107,3 +107,47 @@ def test_bad_framing_sets_status(engines):
     assert st & 2
     _, st = eng.count_host(good)
     assert st == 0
+
+
+@pytest.mark.parametrize("k,mapping", [(7, "varKode"), (9, "cgr")])
+def test_full_size_samples_match_oracle(engines, k, mapping):
+    """BASELINE.json sizes: 1,000,000 reads x 150 bp per sample (320 MB of FASTQ text each),
+    generated on the device.  The oracle counts such a sample in well under a second, so the
+    check is exact: histograms and images bit-identical, for several workgroup splits, plus
+    the size-independent properties (window checksum, linearity under concatenation)."""
+    import torch
+    eng = engines(k, mapping)
+    reads, L = 1_000_000, 150
+    dev, offs, lens = eng.synth(900, 2, reads, L, dist=1)
+    host = dev.cpu().numpy()
+    lut, n = pixel_lut(k, mapping), side(k, mapping)
+    want_h, want_i, nwins = [], [], []
+    for j in range(2):
+        buf = host[int(offs[j]):int(offs[j]) + int(lens[j])]
+        h, nwin, st = oracle.count_fastq(buf, k)
+        assert st == 0
+        want_h.append(h)
+        nwins.append(nwin)
+        want_i.append(oracle.image(oracle.strand_merge(h, k), k, lut, n * n))
+    for parts in (1, 4, 0):
+        img, hist, status = eng.fastq_to_images(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got_h = hist.cpu().numpy().view(np.uint32)
+        got_i = img.cpu().numpy()
+        for j in range(2):
+            assert int(got_h[j].sum(dtype=np.uint64)) == nwins[j]          # window checksum
+            assert np.array_equal(got_h[j], want_h[j]), (parts, j)
+            assert np.array_equal(got_i[j].ravel(), want_i[j]), (parts, j)
+    # linearity: the two samples counted as ONE 640 MB sample = sum of the two histograms
+    both_off = np.array([0], dtype=np.uint64)
+    both_len = np.array([int(lens[0] + lens[1])], dtype=np.uint64)
+    hist, status = eng.count(dev, both_off, both_len)
+    assert not status.cpu().numpy().any()
+    assert np.array_equal(hist.cpu().numpy().view(np.uint32)[0], want_h[0] + want_h[1])
+    # expected window count from the text itself: reads*(L-k+1) minus windows touching an N
+    seq = dev[:int(lens[0])].view(reads, 2 * L + 20)[:, 16:16 + L]
+    isn = (seq == ord("N")).to(torch.int32)
+    cs = torch.cumsum(isn, dim=1)
+    cs = torch.cat([torch.zeros((reads, 1), dtype=cs.dtype, device=cs.device), cs], dim=1)
+    clean = ((cs[:, k:] - cs[:, :-k]) == 0).sum().item()
+    assert clean == nwins[0]

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: two ranks over gloo shard the samples, process their share, and rank 0
+merges the stats; the timing protocol's MAX-reduce is exercised too.  The per-sample work
+is done by the oracle here (this is a test of the sharding, not of the kernels)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_samples, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from oracle import oracle
+    from varkoder_amd import shard, synth
+    from varkoder_amd.mapping import pixel_lut
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_indices(n_samples, rank, world)
+    lut = pixel_lut(5, "cgr")
+    stats = {}
+    for s in mine:
+        img, nwin, st = oracle.fastq_to_image(synth.sample_fastq(s, 200, 150), 5, lut, 1024)
+        stats[f"s{s:03d}"] = {"windows": int(nwin), "img_sum": int(img.astype(np.int64).sum()), "rank": rank}
+    dist.barrier()
+    slow = shard.max_over_ranks(1.0 + rank)          # the bench's "MAX over ranks" timing rule
+    merged = shard.gather_stats(stats, dst=0)
+    if rank == 0:
+        out.put((slow, merged))
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_covers_every_sample_once():
+    from oracle import oracle
+    from varkoder_amd import shard, synth
+    from varkoder_amd.mapping import pixel_lut
+    n, world = 7, 2
+    assert shard.shard_indices(n, 0, 2) == [0, 2, 4, 6] and shard.shard_indices(n, 1, 2) == [1, 3, 5]
+    with pytest.raises(ValueError):
+        shard.shard_indices(n, 2, 2)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    slow, merged = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert slow == 2.0
+    assert list(merged.keys()) == [f"s{s:03d}" for s in range(n)]
+    lut = pixel_lut(5, "cgr")
+    for s in range(n):
+        img, nwin, st = oracle.fastq_to_image(synth.sample_fastq(s, 200, 150), 5, lut, 1024)
+        got = merged[f"s{s:03d}"]
+        assert got["windows"] == nwin and got["img_sum"] == int(img.astype(np.int64).sum())
+        assert got["rank"] == s % world
+
+
+def test_single_process_helpers_are_identity():
+    from varkoder_amd import shard
+    assert shard.max_over_ranks(3.5) == 3.5
+    assert shard.gather_stats({"a": {"x": 1}}) == {"a": {"x": 1}}
+    assert shard.world_info()[1] >= 1

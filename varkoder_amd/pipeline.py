@@ -1,0 +1,115 @@
+"""Batched steps D+E of run_clean2img (commands/image.py:1054-1127) for already cleaned and
+split FASTQ files: many files per launch, images written by a host thread pool, optional
+sharding over the ranks of a torch.distributed job.
+
+Steps B/C of the reference (fastp, reformat.sh) are external tools that are out of this
+path's scope; this module enters where the reference enters step D: with
+files named `<sample>@<bp>K.fq[.gz]` as split_fastq leaves them (image.py:699-709).
+"""
+import hashlib
+import time
+from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+from .config import BP_KMER_SEP, LABELS_SEP, QUAL_THRESH
+from .image import eprint, read_fastq_bytes
+from .shard import shard_indices
+
+
+def image_name(fastq_path, k, mapping_code):
+    """`<sample>@<bp>K+<mapping>+k<k>.png` (image.py:752-759 then :840-849)."""
+    p = Path(fastq_path)
+    stem = str(p.name.removesuffix("".join(p.suffixes)))
+    return stem + BP_KMER_SEP + mapping_code + BP_KMER_SEP + "k" + str(k) + ".png"
+
+
+def save_png(arr, path, labels, base_sd, base_sd_thresh, mapping_code):
+    from PIL import Image
+    from PIL.PngImagePlugin import PngInfo
+    meta = PngInfo()  # image.py:923-927, same keys in the same order
+    meta.add_text("varkoderKeywords", LABELS_SEP.join(labels))
+    meta.add_text("varkoderBaseFreqSd", str(base_sd))
+    meta.add_text("varkoderLowQualityFlag", str(base_sd > base_sd_thresh))
+    meta.add_text("varkoderMapping", mapping_code)
+    Image.fromarray(arr).save(path, optimize=True, pnginfo=meta)
+
+
+def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_sd=None, overwrite=False,
+                     subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=2 << 30, io_threads=8,
+                     engine=None, verbose=False):
+    """Process this rank's share of `files`.  Returns {sample_file_stem: OrderedDict(stats)}
+    with the reference's stats keys `<k>mer_counting_time` and `k<k>_img_time` (per-file
+    share of the batch wall time) or `failed_step` for files whose FASTQ framing is bad."""
+    from .engine import ImageEngine
+    files = [Path(f) for f in files]
+    labels = labels or {}
+    base_sd = base_sd or {}
+    mine = [files[i] for i in shard_indices(len(files), rank, world)]
+    eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
+    outdir = Path(outdir)
+    outdir.mkdir(parents=True, exist_ok=True)
+    stats = OrderedDict()
+    pool = ThreadPoolExecutor(io_threads)
+    pending = []
+
+    def target(f):
+        name = image_name(f, k, mapping_code)
+        d = outdir
+        if subfolder_levels:
+            hsh = list(hashlib.md5(name.encode("UTF-8")).hexdigest())
+            for _ in range(subfolder_levels):
+                d = d / hsh.pop()
+        return d, name
+
+    todo = []
+    for f in mine:
+        d, name = target(f)
+        if not overwrite and (d / name).is_file():
+            eprint("File exists. Skipping image for file:", str(f))
+            continue
+        todo.append(f)
+
+    i = 0
+    while i < len(todo):
+        batch, nbytes = [], 0
+        t0 = time.perf_counter()
+        for data, f in zip(pool.map(read_fastq_bytes, todo[i:i + 4 * io_threads]), todo[i:]):
+            if batch and nbytes + len(data) > batch_bytes:
+                break
+            batch.append((f, data))
+            nbytes += len(data)
+        i += len(batch)
+        dev, offs, lens = eng.upload([d for _, d in batch])
+        t1 = time.perf_counter()
+        img, hist, status = eng.fastq_to_images(dev, offs, lens)
+        st = status.cpu().numpy()
+        imgs = img.cpu().numpy()
+        nz = (hist != 0).any(dim=1).cpu().numpy()
+        t2 = time.perf_counter()
+        for j, (f, _) in enumerate(batch):
+            key = str(f.name.removesuffix("".join(f.suffixes)))
+            s = stats.setdefault(key, OrderedDict())
+            if st[j] or not nz[j]:
+                eprint("K-MER COUNTING FAIL, SKIPPING FILE:", f)
+                s["failed_step"] = "image"
+                continue
+            s[str(k) + "mer_counting_time"] = (t2 - t0) / len(batch)
+            d, name = target(f)
+            d.mkdir(parents=True, exist_ok=True)
+            sample = key.split("@")[0]
+            sd = base_sd.get(sample, 0)
+            pending.append((key, time.perf_counter(),
+                            pool.submit(save_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
+                                        QUAL_THRESH, mapping_code)))
+        if verbose:
+            eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
+    for key, t, fut in pending:
+        fut.result()
+        stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t
+    pool.shutdown()
+    if engine is None:
+        eng.close()
+    return stats

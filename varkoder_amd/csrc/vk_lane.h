@@ -116,11 +116,11 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
             const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
             const uint32_t x = L ^ (t & 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
             C |= (x & 0x03030303u) << (2 * j);
-            const uint32_t y = x & 0xFCFCFCFCu;
-            const uint32_t nz = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y;  // bit 7: not a base
+            // bit 7 := byte is not a base: some bit of x & 0x7C set (carry trick) or bit 7 of x
+            const uint32_t nz = ((x & 0x7C7C7C7Cu) + 0x7F7F7F7Fu) | x;
             IV |= (nz >> (7 - 2 * j)) & (0x01010101u << (2 * j));
-            const uint32_t z = t ^ 0x0A0A0A0Au;
-            const uint32_t nn = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;  // bit 7: not '\n'
+            // bit 7 := byte is not '\n'  ((t7 ^ 0x0A) + 0x7F is one v_xad_u32)
+            const uint32_t nn = (((t & 0x7F7F7F7Fu) ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu) | t;
             NN |= (nn >> (7 - 2 * j)) & (0x01010101u << (2 * j));
         }
         o.C[g] = C;
@@ -213,16 +213,28 @@ VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit
     // space and un-reverses at flush time (see vk_count_kernel); here the raw field.
     const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+    // OK bits are consumed from the top with x += x: the carry-out IS the lane predicate
+    // (one v_add_co_u32 per position instead of and + compare).  OK lives on even bits, so two
+    // dwords are interleaved (odd bits = the next dword) and every carry is a real position.
+    uint32_t w[2] = {ok[0] | (ok[1] << 1), ok[2] | (ok[3] << 1)};
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int p = 0; p < 64; ++p) {
-        const int o = 30 + 2 * (p - K + 1);  // bit offset of (field << 2) in v[]
-        const int word = o >> 5, sh = o & 31;
-        uint32_t val;
-        if (sh + 2 * K + 2 <= 32) val = v[word] >> sh;
-        else val = alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
-        if (ok[p >> 4] & (1u << (2 * (p & 15)))) emit(val & kMask4);
+    for (int t = 0; t < 32; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int h = 0; h < 2; ++h) {
+            const int g = (t & 1) ? 2 * h : 2 * h + 1;   // bit 31-t: odd bits belong to dword 2h+1
+            const int p = 16 * g + 15 - (t >> 1);
+            const int o = 30 + 2 * (p - K + 1);           // bit offset of (field << 2) in v[]
+            const int word = o >> 5, sh = o & 31;
+            uint32_t val;
+            if (sh + 2 * K + 2 <= 32) val = v[word] >> sh;
+            else val = alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+            const bool take = __builtin_add_overflow(w[h], w[h], &w[h]);
+            if (take) emit(val & kMask4);
+        }
     }
 }
 

@@ -61,6 +61,34 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// --- DPP cross-lane moves (gfx9: row_shr, row_bcast15/31, wave_shr) ---------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x) {
+    // lanes whose source is out of range or whose row is masked receive 0
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, ROW_MASK, 0xF, false));
+}
+
+// inclusive prefix sum over the 64 lanes: 4 row_shr steps inside rows of 16, then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3 -- six v_add_u32 with DPP operands
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += dpp_or_zero<0x111, 0xF>(x);
+    x += dpp_or_zero<0x112, 0xF>(x);
+    x += dpp_or_zero<0x114, 0xF>(x);
+    x += dpp_or_zero<0x118, 0xF>(x);
+    x += dpp_or_zero<0x142, 0xA>(x);
+    x += dpp_or_zero<0x143, 0xC>(x);
+    return x;
+}
+
+// value of lane-1 (lane 0 receives `first`): wave_shr:1
+__device__ __forceinline__ uint32_t wave_prev_lane(uint32_t x, uint32_t first) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(first), static_cast<int>(x), 0x138, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t x, int lane) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), lane));
+}
+
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
 __device__ __forceinline__ uint4 zero4() { return make_uint4(0u, 0u, 0u, 0u); }
@@ -247,14 +275,9 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             const uint32_t c = vkl::classify(d, lb);
 
             // newline prefix over the wave -> line phase at the start of each lane's block
-            uint32_t incl = c;
-#pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                uint32_t t = __shfl_up(incl, dd);
-                if (lane >= dd) incl += t;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            if (it == 0) pph = ph0 - __shfl(c, 0);  // the pre-block's newlines precede w0
+            const uint32_t incl = wave_inclusive_sum(c);
+            const uint32_t total = lane_bcast(incl, 63);
+            if (it == 0) pph = ph0 - lane_bcast(c, 0);  // the pre-block's newlines precede w0
             const uint32_t lph = (pph + incl - c) & 3u;
 
             vkl::Mask128 seq;
@@ -263,10 +286,10 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             uint32_t bad[4], ok[4];
             vkl::bad_mask(lb, seq, bad);
 
-            uint32_t badh = __shfl_up(bad[3], 1), ch = __shfl_up(lb.C[3], 1);
-            if (lane == 0) { badh = carry_bad; ch = carry_c; }
-            carry_bad = __shfl(bad[3], 63);
-            carry_c = __shfl(lb.C[3], 63);
+            const uint32_t badh = wave_prev_lane(bad[3], carry_bad);
+            const uint32_t ch = wave_prev_lane(lb.C[3], carry_c);
+            carry_bad = lane_bcast(bad[3], 63);
+            carry_c = lane_bcast(lb.C[3], 63);
 
             vkl::ok_mask<K>(badh, bad, ok);
             if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }

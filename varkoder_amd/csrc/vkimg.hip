@@ -231,13 +231,25 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
         const long long o0 = static_cast<long long>(w0) - 64;
         const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
         uint4 r0, r1, r2, r3;
-        {
-            long long p = o0 + static_cast<long long>(lane) * 16;
-            r0 = load_granule_s(sbase, p, w1);
-            r1 = load_granule_s(sbase, p + 1024, w1);
-            r2 = load_granule_s(sbase, p + 2048, w1);
-            r3 = load_granule_s(sbase, p + 3072, w1);
-        }
+        // A piece that lies wholly inside [0, w1) (all but the first and last of a range) is
+        // loaded with four unguarded 16-byte loads off one address; edge pieces zero-fill.
+        auto load_piece = [&](uint64_t piece) {
+            const long long pb = o0 + static_cast<long long>(piece) * kPiece;
+            if (pb >= 0 && static_cast<uint64_t>(pb) + kPiece <= w1) {  // wave-uniform
+                const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + lane;
+                r0 = g[0];
+                r1 = g[64];
+                r2 = g[128];
+                r3 = g[192];
+            } else {
+                const long long p = pb + static_cast<long long>(lane) * 16;
+                r0 = load_granule_s(sbase, p, w1);
+                r1 = load_granule_s(sbase, p + 1024, w1);
+                r2 = load_granule_s(sbase, p + 2048, w1);
+                r3 = load_granule_s(sbase, p + 3072, w1);
+            }
+        };
+        load_piece(0);
         uint32_t carry_c = 0u, carry_bad = 0x55555555u;
         uint32_t pph = 0;  // line phase at the start of the current piece
         auto tbl = [&](uint32_t q) {
@@ -262,13 +274,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             wave_lds_fence();
             uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
             wave_lds_fence();
-            if (it + 1 < npieces) {  // prefetch the next piece under the SWAR work
-                long long p = o0 + static_cast<long long>(it + 1) * kPiece + static_cast<long long>(lane) * 16;
-                r0 = load_granule_s(sbase, p, w1);
-                r1 = load_granule_s(sbase, p + 1024, w1);
-                r2 = load_granule_s(sbase, p + 2048, w1);
-                r3 = load_granule_s(sbase, p + 3072, w1);
-            }
+            if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
             const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                     q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             vkl::LaneBits lb;

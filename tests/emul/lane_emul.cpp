@@ -66,10 +66,16 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                 }
                 vkl::LaneBits lb[64];
                 uint32_t c[64], total = 0;
+                bool non_ascii = false;  // the kernel's __any(has_non_ascii)
                 for (int lane = 0; lane < 64; ++lane) {
                     uint32_t d[16];
                     memcpy(d, piece + 64 * lane, 64);
-                    c[lane] = vkl::classify(d, lb[lane]);
+                    non_ascii |= vkl::has_non_ascii(d);
+                }
+                for (int lane = 0; lane < 64; ++lane) {
+                    uint32_t d[16];
+                    memcpy(d, piece + 64 * lane, 64);
+                    c[lane] = non_ascii ? vkl::classify<false>(d, lb[lane]) : vkl::classify<true>(d, lb[lane]);
                     total += c[lane];
                 }
                 if (it == 0) pph = ph0 - c[0];

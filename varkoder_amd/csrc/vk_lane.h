@@ -70,6 +70,39 @@ VKL_FN uint32_t popc(uint32_t x) {
 
 VKL_FN uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
+// Three-operand VALU forms that hipcc does not select on gfx950 when one operand is a 32-bit
+// literal (VOP3 cannot encode literals on gfx9): spelled out, with the constant in an SGPR.
+// Plain VGPR-to-VGPR ALU instructions: no memory access, no extra wait states.
+VKL_FN uint32_t and_or_k(uint32_t a, uint32_t kmask, uint32_t c) {  // (a & kmask) | c
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(kmask), "v"(c));
+    return d;
+#else
+    return (a & kmask) | c;
+#endif
+}
+
+VKL_FN uint32_t xor_add_k(uint32_t a, uint32_t kx, uint32_t vadd) {  // (a ^ kx) + vadd
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(kx), "v"(vadd));
+    return d;
+#else
+    return (a ^ kx) + vadd;
+#endif
+}
+
+VKL_FN uint32_t xor_and_k(uint32_t a, uint32_t b, uint32_t kmask) {  // a ^ (b & kmask)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x78" : "=v"(d) : "v"(a), "v"(b), "s"(kmask));
+    return d;
+#else
+    return a ^ (b & kmask);
+#endif
+}
+
 struct LaneBits {
     uint32_t C[4];
     uint32_t IV[4];
@@ -91,10 +124,20 @@ VKL_FN Mask128 ones_below(uint32_t q) {
     return m;
 }
 
+// Bit 7 of some byte set?  (FASTQ is ASCII; the all-ASCII case takes a shorter path.)
+VKL_FN bool has_non_ascii(const uint32_t d[16]) {
+    uint32_t o = 0;
+    for (int i = 0; i < 16; ++i) o |= d[i];
+    return (o & 0x80808080u) != 0u;
+}
+
 // Phase A: classify the 64 bytes.  Returns the number of newlines in the block.
+// ASCII = true may only be used when no byte of the block has bit 7 set.
+template <bool ASCII>
 VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
     constexpr uint32_t kLutLo = 0x41204020u;  // low3 = 0..3 : inv, A(0x40|0), inv, C(0x40|1)
     constexpr uint32_t kLutHi = 0x42202053u;  // low3 = 4..7 : T(0x50|3), inv, inv, G(0x40|2)
+    const uint32_t k7f = 0x7F7F7F7Fu;
     uint32_t c = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -114,14 +157,16 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
             const uint32_t t = T[j];
             // table lookup on the low 3 bits: expected high bits (case folded) | code
             const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
-            const uint32_t x = L ^ (t & 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
-            C |= (x & 0x03030303u) << (2 * j);
-            // bit 7 := byte is not a base: some bit of x & 0x7C set (carry trick) or bit 7 of x
-            const uint32_t nz = ((x & 0x7C7C7C7Cu) + 0x7F7F7F7Fu) | x;
-            IV |= (nz >> (7 - 2 * j)) & (0x01010101u << (2 * j));
-            // bit 7 := byte is not '\n'  ((t7 ^ 0x0A) + 0x7F is one v_xad_u32)
-            const uint32_t nn = (((t & 0x7F7F7F7Fu) ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu) | t;
-            NN |= (nn >> (7 - 2 * j)) & (0x01010101u << (2 * j));
+            const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
+            C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+            // bit 7 := byte is not a base: some bit of x & 0x7C set (carry trick), or bit 7 of x
+            uint32_t nz = (x & 0x7C7C7C7Cu) + k7f;
+            if (!ASCII) nz |= x;
+            IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+            // bit 7 := byte is not '\n': low 7 bits differ from 0x0A, or bit 7 of t
+            uint32_t nn = xor_add_k(t & k7f, 0x0A0A0A0Au, k7f);
+            if (!ASCII) nn |= t;
+            NN = and_or_k(nn >> (7 - 2 * j), 0x01010101u << (2 * j), NN);
         }
         o.C[g] = C;
         o.IV[g] = IV;
@@ -151,9 +196,12 @@ VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Tbl tbl) {
     m = tbl(umin(p2 + 1u, 64u));
     r[0] &= ~m.w[0]; r[1] &= ~m.w[1]; r[2] &= ~m.w[2]; r[3] &= ~m.w[3];
     const uint32_t p3 = first_newline(r);
-    // interval [s, e): after the d-th newline, up to the (d+1)-th
-    const uint32_t s = d == 0 ? 0u : (d == 1 ? p1 + 1u : (d == 2 ? p2 + 1u : p3 + 1u));
-    const uint32_t e = d == 0 ? p1 : (d == 1 ? p2 : (d == 2 ? p3 : 64u));
+    // interval [s, e): after the d-th newline, up to the (d+1)-th.  The five candidates
+    // (-1, p1, p2, p3, 64) sit in consecutive bytes; a funnel shift by 8d picks the pair.
+    const uint32_t lo = 0xFFu | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    const uint32_t pr = alignbit(64u, lo, 8u * d);
+    const uint32_t s = ((pr & 0xFFu) + 1u) & 0xFFu;
+    const uint32_t e = (pr >> 8) & 0xFFu;
     const Mask128 ms = tbl(umin(s, 64u)), me = tbl(umin(e, 64u));
     Mask128 out;
     for (int g = 0; g < 4; ++g) out.w[g] = me.w[g] & ~ms.w[g];
@@ -213,27 +261,48 @@ VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit
     // space and un-reverses at flush time (see vk_count_kernel); here the raw field.
     const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
-    // OK bits are consumed from the top with x += x: the carry-out IS the lane predicate
-    // (one v_add_co_u32 per position instead of and + compare).  OK lives on even bits, so two
-    // dwords are interleaved (odd bits = the next dword) and every carry is a real position.
-    uint32_t w[2] = {ok[0] | (ok[1] << 1), ok[2] | (ok[3] << 1)};
+    // OK bits are consumed from the top with x += x: the carry-out IS the lane predicate (one
+    // v_add_co_u32 per position instead of and + compare).  OK lives on even bits; the odd bits
+    // of w carry the same dword rotated by 8 positions, so that consecutive carries deliver
+    // positions i-8 and i of one dword, whose fields lie 16 bits apart in ONE extracted word
+    // (for K <= 7): one funnel shift serves two positions, the upper one through an SDWA and.
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int t = 0; t < 32; ++t) {
+    for (int g = 0; g < 4; ++g) {
+        uint32_t w = ok[g] | (alignbit(ok[g], ok[g], 16u) << 1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int h = 0; h < 2; ++h) {
-            const int g = (t & 1) ? 2 * h : 2 * h + 1;   // bit 31-t: odd bits belong to dword 2h+1
-            const int p = 16 * g + 15 - (t >> 1);
-            const int o = 30 + 2 * (p - K + 1);           // bit offset of (field << 2) in v[]
+        for (int i = 15; i >= 8; --i) {
+            // bit 31 first: odd bit 2i+1 = position (i + 8) % 16 = i - 8; then even bit 2i = position i
+            const int plo = 16 * g + i - 8, phi = 16 * g + i;
+            const int o = 30 + 2 * (plo - K + 1);  // bit offset of (field << 2) of plo in v[]
             const int word = o >> 5, sh = o & 31;
-            uint32_t val;
-            if (sh + 2 * K + 2 <= 32) val = v[word] >> sh;
-            else val = alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
-            const bool take = __builtin_add_overflow(w[h], w[h], &w[h]);
-            if (take) emit(val & kMask4);
+            if (2 * K + 2 <= 16) {
+                uint32_t x;  // 32 bits from offset o: field(plo) << 2 at [0,16), field(phi) << 2 at [16,32)
+                if (sh == 0) x = v[word];
+                else if (word == 4) x = v[4] >> sh;  // the last fields end exactly at bit 160
+                else x = alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+                const bool take_lo = __builtin_add_overflow(w, w, &w);
+                if (take_lo) emit(x & kMask4);
+                const bool take_hi = __builtin_add_overflow(w, w, &w);
+                if (take_hi) emit((x >> 16) & kMask4);
+            } else {
+                const int o2 = o + 16, word2 = o2 >> 5, sh2 = o2 & 31;
+                const bool take_lo = __builtin_add_overflow(w, w, &w);
+                if (take_lo) {
+                    const uint32_t x = (sh + 2 * K + 2 <= 32) ? (v[word] >> sh)
+                                                               : alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+                    emit(x & kMask4);
+                }
+                const bool take_hi = __builtin_add_overflow(w, w, &w);
+                if (take_hi) {
+                    const uint32_t x = (sh2 + 2 * K + 2 <= 32) ? (v[word2] >> sh2)
+                                                                : alignbit(v[word2 + 1], v[word2], static_cast<uint32_t>(sh2));
+                    emit(x & kMask4);
+                }
+            }
         }
     }
 }

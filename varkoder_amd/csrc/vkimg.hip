@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                     q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             vkl::LaneBits lb;
-            const uint32_t c = vkl::classify(d, lb);
+            const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
 
             // newline prefix over the wave -> line phase at the start of each lane's block
             const uint32_t incl = wave_inclusive_sum(c);

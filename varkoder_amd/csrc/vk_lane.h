@@ -52,9 +52,12 @@ VKL_FN uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
 }
 
 VKL_FN uint32_t ffbl(uint32_t x) {
-    // index of the lowest set bit, 0xFFFFFFFF for zero (v_ffbl_b32)
+    // index of the lowest set bit, 0xFFFFFFFF for zero: exactly v_ffbl_b32 (spelled out: __ffs
+    // wraps it in a compare + select for the zero case, which the hardware already handles)
 #if defined(__HIP_DEVICE_COMPILE__)
-    return static_cast<uint32_t>(__ffs(static_cast<int>(x)) - 1);
+    uint32_t d;
+    asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
 #else
     return x ? static_cast<uint32_t>(__builtin_ctz(x)) : 0xFFFFFFFFu;
 #endif
@@ -185,16 +188,17 @@ VKL_FN uint32_t first_newline(const uint32_t nl[4]) {
 
 // Sequence-line mask of a block with at most three newlines (the normal case: at most
 // one stretch of sequence per 64 bytes).  lph = line phase at the block start
-// (0 header, 1 sequence, 2 plus, 3 quality).  tbl(q) = ones_below(q).
-template <typename Tbl>
-VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Tbl tbl) {
+// (0 header, 1 sequence, 2 plus, 3 quality).  below(q) = ones_below(q), above(q) = ~below(q);
+// the kernel serves both from LDS tables (one ds_read_b128 each).
+template <typename Below, typename Above>
+VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Above above) {
     const uint32_t d = (1u - lph) & 3u;  // newlines to skip before a sequence line starts
     const uint32_t p1 = first_newline(NL);
-    Mask128 m = tbl(umin(p1 + 1u, 64u));
-    uint32_t r[4] = {NL[0] & ~m.w[0], NL[1] & ~m.w[1], NL[2] & ~m.w[2], NL[3] & ~m.w[3]};
+    Mask128 m = above(umin(p1 + 1u, 64u));
+    uint32_t r[4] = {NL[0] & m.w[0], NL[1] & m.w[1], NL[2] & m.w[2], NL[3] & m.w[3]};
     const uint32_t p2 = first_newline(r);
-    m = tbl(umin(p2 + 1u, 64u));
-    r[0] &= ~m.w[0]; r[1] &= ~m.w[1]; r[2] &= ~m.w[2]; r[3] &= ~m.w[3];
+    m = above(umin(p2 + 1u, 64u));
+    r[0] &= m.w[0]; r[1] &= m.w[1]; r[2] &= m.w[2]; r[3] &= m.w[3];
     const uint32_t p3 = first_newline(r);
     // interval [s, e): after the d-th newline, up to the (d+1)-th.  The five candidates
     // (-1, p1, p2, p3, 64) sit in consecutive bytes; a funnel shift by 8d picks the pair.
@@ -202,10 +206,16 @@ VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Tbl tbl) {
     const uint32_t pr = alignbit(64u, lo, 8u * d);
     const uint32_t s = ((pr & 0xFFu) + 1u) & 0xFFu;
     const uint32_t e = (pr >> 8) & 0xFFu;
-    const Mask128 ms = tbl(umin(s, 64u)), me = tbl(umin(e, 64u));
+    const Mask128 ms = above(umin(s, 64u)), me = below(umin(e, 64u));
     Mask128 out;
-    for (int g = 0; g < 4; ++g) out.w[g] = me.w[g] & ~ms.w[g];
+    for (int g = 0; g < 4; ++g) out.w[g] = me.w[g] & ms.w[g];
     return out;
+}
+
+VKL_FN Mask128 ones_not_below(uint32_t q) {
+    Mask128 m = ones_below(q);
+    for (int g = 0; g < 4; ++g) m.w[g] = ~m.w[g];
+    return m;
 }
 
 // Any number of newlines (degenerate FASTQ with very short lines): position by position.

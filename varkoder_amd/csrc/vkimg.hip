@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     __shared__ uint32_t hist[BINS];
     __shared__ uint4 stage[kWaves][kPiece / 16];
     __shared__ uint4 below[66];  // below[q] = bits [0, 2q) of a 128-bit string
+    __shared__ uint4 above[66];  // above[q] = ~below[q]
 
     // block -> (unit = (sample, part), histogram part); the HPARTS siblings of a
     // unit get block ids that differ by multiples of 8, i.e. share an XCD's L2.
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     if (tid < 66) {
         vkl::Mask128 m = vkl::ones_below(static_cast<uint32_t>(tid));
         below[tid] = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
+        above[tid] = make_uint4(~m.w[0], ~m.w[1], ~m.w[2], ~m.w[3]);
     }
     __syncthreads();
 
@@ -252,8 +254,14 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
         load_piece(0);
         uint32_t carry_c = 0u, carry_bad = 0x55555555u;
         uint32_t pph = 0;  // line phase at the start of the current piece
-        auto tbl = [&](uint32_t q) {
+        auto tbl_below = [&](uint32_t q) {
             uint4 v = below[q];
+            vkl::Mask128 m;
+            m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+            return m;
+        };
+        auto tbl_above = [&](uint32_t q) {
+            uint4 v = above[q];
             vkl::Mask128 m;
             m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
             return m;
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
 
             vkl::Mask128 seq;
             if (__any(c > 3u)) seq = vkl::seq_mask_general(lb.NL, lph);
-            else seq = vkl::seq_mask_fast(lb.NL, lph, tbl);
+            else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above);
             uint32_t bad[4], ok[4];
             vkl::bad_mask(lb, seq, bad);
 
@@ -663,7 +671,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     uint32_t grid = ((units + 7u) / 8u) * 8u * HP;
     ctx->last_grid = grid;
     ctx->last_block = kCountThreads;
-    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece + 66 * 16;
+    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece + 2 * 66 * 16;
     hipLaunchKernelGGL((vk_count_kernel<K, LP>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
                        d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
     VK_HIP(ctx, hipGetLastError());

@@ -103,6 +103,15 @@ int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img);
 int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t nsamples,
                           uint32_t reads, uint32_t readlen, uint64_t seed, int dist);
 
+/* Replaces remap() of `varKoder convert` (commands/convert.py:34-77) for a batch of host
+ * images: out[p] = in[src0[p]] (src 0xFFFFFFFF = pixel without a k-mer -> 0); with sum_rc the
+ * uint8-wrapping sum w0[p]*in[src0[p]] + w1[p]*in[src1[p]] followed by the reference's
+ * (v - min) / max * 255 rescale in float64.  The source maps are built by
+ * varkoder_amd/convert.py from the two k-mer mappings. */
+int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t npix_in,
+                  uint32_t npix_out, const uint32_t* src0, const uint32_t* src1,
+                  const uint8_t* w0, const uint8_t* w1, int sum_rc, uint8_t* img_out);
+
 /* Introspection used by bench.py / tests: workgroups and LDS bytes of the last
  * vk_count_device launch. */
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes);

@@ -1,0 +1,92 @@
+"""`convert`'s remap: the source-map rule (host logic) and the gather kernel,
+pinned on outputs of the reference's own remap() and on the six example PNGs of docs/."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import vectors
+from varkoder_amd import convert
+from varkoder_amd.mapping import side
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def numpy_remap(img, k, a, b, sum_rc):
+    """Apply convert.source_maps with NumPy (checks the map-building rule without a GPU)."""
+    s0, s1, w0, w1, nin, nout = convert.source_maps(k, a, b)
+    flat = np.concatenate([img.ravel(), np.zeros(1, np.uint8)])     # index -1 -> 0 for unmapped
+    i0 = np.where(s0 == 0xFFFFFFFF, nin, s0).astype(np.int64)
+    i1 = np.where(s1 == 0xFFFFFFFF, nin, s1).astype(np.int64)
+    n = side(k, b)
+    if not sum_rc:
+        return flat[i0].reshape(n, n)
+    acc = ((flat[i0].astype(np.uint32) * w0 + flat[i1].astype(np.uint32) * w1) & 0xFF).astype(np.uint8)
+    out = np.uint8((acc - acc.min()) / acc.max() * 255)
+    return out.reshape(n, n)
+
+
+def cases():
+    for k in (5, 6, 7):
+        for a, b, s in (("cgr", "varKode", False), ("cgr", "varKode", True), ("varKode", "cgr", False)):
+            yield k, a, b, s
+
+
+def input_image(k, a):
+    return vectors.random_image(side(k, a), seed=k * 10 + (1 if a == "cgr" else 2))
+
+
+@pytest.mark.parametrize("k,a,b,sum_rc", list(cases()))
+def test_source_map_rule_reproduces_reference_remap(manifest, golden_small, k, a, b, sum_rc):
+    key = f"k{k}_{a}_to_{b}" + ("_sumrc" if sum_rc else "")
+    got = numpy_remap(input_image(k, a), k, a, b, sum_rc)
+    assert list(got.shape) == manifest["remap_cases"][key]["shape"]
+    if "remap_" + key in golden_small:
+        assert np.array_equal(got, golden_small["remap_" + key])
+    assert sha(got) == manifest["remap_cases"][key]["sha256"]
+
+
+def _docs_pairs():
+    from PIL import Image
+    for vk in sorted(glob.glob(os.path.join(GOLDEN, "docs_*+varKode+k7.png"))):
+        cg = vk.replace("+varKode+", "+cgr+")
+        yield np.array(Image.open(vk)), np.array(Image.open(cg))
+
+
+def test_docs_example_images_are_consistent_with_the_maps(manifest):
+    """docs/*+cgr+k7.png were made by `convert` from docs/*+varKode+k7.png: remapping the
+    varKode image must give the cgr image exactly; the way back differs only in the 89
+    varKode cells that no k-mer maps to."""
+    pairs = list(_docs_pairs())
+    assert len(pairs) == 3
+    for vk, cg in pairs:
+        assert np.array_equal(numpy_remap(vk, 7, "varKode", "cgr", False), cg)
+        back = numpy_remap(cg, 7, "cgr", "varKode", False)
+        assert int((back != vk).sum()) == 91 * 91 - 8192 == 89
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,a,b,sum_rc", list(cases()))
+def test_remap_kernel_equals_reference(manifest, k, a, b, sum_rc):
+    key = f"k{k}_{a}_to_{b}" + ("_sumrc" if sum_rc else "")
+    got = convert.remap_array(input_image(k, a), k, a, b, sum_rc)
+    assert sha(got) == manifest["remap_cases"][key]["sha256"]
+    batch = np.stack([input_image(k, a), input_image(k, a)[::-1].copy()])
+    out = convert.remap_array(batch, k, a, b, sum_rc)
+    assert np.array_equal(out[0], got)
+    assert np.array_equal(out[1], numpy_remap(batch[1], k, a, b, sum_rc))
+
+
+@pytest.mark.gpu
+def test_remap_kernel_on_docs_images():
+    from PIL import Image
+    for vk, cg in _docs_pairs():
+        assert np.array_equal(np.array(convert.remap(Image.fromarray(vk), 7, "varKode", "cgr")), cg)
+    with pytest.raises(Exception, match="Input and output mapping must be one of"):
+        convert.remap_array(np.zeros((32, 32), np.uint8), 5, "cgr", "nope")

@@ -76,3 +76,11 @@ def class_totals(fwd, k):
     tot = np.where(rc == np.arange(4 ** k), fwd, fwd + fwd[rc])
     assert tot.max() < 2 ** 32 - 1
     return tot.astype(np.uint32)
+
+
+def random_image(side, seed):
+    """Asymmetric pseudo-random uint8 image (used to pin remap's duplicate-resolution order)."""
+    idx = np.arange(side * side, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = splitmix64(idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed))
+    return (h & np.uint64(0xFF)).astype(np.uint8).reshape(side, side)

@@ -583,6 +583,55 @@ __global__ void vk_synth_kernel(uint8_t* __restrict__ out, uint32_t sample0, uin
     }
 }
 
+// ----------------------------------------------------------------- remap ----
+// convert.py:34-77 as a gather: out[p] = in[src0[p]] (0xFFFFFFFF = unmapped -> 0), or with
+// sum_rc the uint8-wrapping weighted sum of two source pixels followed by the reference's
+// float64 min/max rescale.  One workgroup per image.
+__global__ __launch_bounds__(256) void vk_remap_kernel(const uint8_t* __restrict__ in, uint32_t npix_in,
+                                                        uint32_t npix_out, const uint32_t* __restrict__ src0,
+                                                        const uint32_t* __restrict__ src1,
+                                                        const uint8_t* __restrict__ w0, const uint8_t* __restrict__ w1,
+                                                        int sum_rc, uint8_t* __restrict__ out) {
+    __shared__ uint32_t red_min[256], red_max[256];
+    const uint8_t* img = in + static_cast<uint64_t>(blockIdx.x) * npix_in;
+    uint8_t* o = out + static_cast<uint64_t>(blockIdx.x) * npix_out;
+    const uint32_t tid = threadIdx.x;
+    if (!sum_rc) {
+        for (uint32_t p = tid; p < npix_out; p += 256) {
+            uint32_t s0 = src0[p];
+            o[p] = s0 == 0xFFFFFFFFu ? 0 : img[s0];
+        }
+        return;
+    }
+    uint32_t mn = 255, mx = 0;
+    for (uint32_t p = tid; p < npix_out; p += 256) {
+        uint32_t s0 = src0[p], s1 = src1[p];
+        uint32_t a = s0 == 0xFFFFFFFFu ? 0u : img[s0], b = s1 == 0xFFFFFFFFu ? 0u : img[s1];
+        uint32_t v = (a * w0[p] + b * w1[p]) & 0xFFu;  // np.add.at on a uint8 array wraps
+        o[p] = static_cast<uint8_t>(v);
+        mn = min(mn, v);
+        mx = max(mx, v);
+    }
+    red_min[tid] = mn;
+    red_max[tid] = mx;
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            red_min[tid] = min(red_min[tid], red_min[tid + st]);
+            red_max[tid] = max(red_max[tid], red_max[tid + st]);
+        }
+        __syncthreads();
+    }
+    mn = red_min[0];
+    mx = red_max[0];
+    for (uint32_t p = tid; p < npix_out; p += 256) {
+        uint32_t v = o[p];
+        // np.uint8((arr - arr.min()) / arr.max() * 255): float64 divide, multiply, truncate
+        double r = mx ? static_cast<double>(v - mn) / static_cast<double>(mx) * 255.0 : 0.0;
+        o[p] = static_cast<uint8_t>(static_cast<uint32_t>(r));
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI ------
@@ -890,6 +939,44 @@ int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t n
     hipLaunchKernelGGL(vk_synth_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, ctx->stream,
                        static_cast<uint8_t*>(d_out), sample0, nsamples, reads, readlen, seed, dist, total16);
     VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t npix_in, uint32_t npix_out,
+                  const uint32_t* src0, const uint32_t* src1, const uint8_t* w0, const uint8_t* w1, int sum_rc,
+                  uint8_t* img_out) {
+    if (!ctx || !img_in || !img_out || !src0 || npix_in == 0 || npix_out == 0) return VK_EINVAL;
+    if (sum_rc && (!src1 || !w0 || !w1)) return VK_EINVAL;
+    if (nimg == 0) return VK_OK;
+    for (uint32_t p = 0; p < npix_out; ++p) {
+        if (src0[p] != 0xFFFFFFFFu && src0[p] >= npix_in) return VK_EINVAL;
+        if (sum_rc && src1[p] != 0xFFFFFFFFu && src1[p] >= npix_in) return VK_EINVAL;
+    }
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_b = static_cast<size_t>(nimg) * npix_in, out_b = static_cast<size_t>(nimg) * npix_out;
+    const size_t lut_b = static_cast<size_t>(npix_out) * 4;
+    const size_t need = in_b + out_b + 2 * lut_b + 2 * npix_out + 256;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_stage), &ctx->stage_cap, need);
+    if (rc) return rc;
+    uint8_t* base = ctx->d_stage;
+    uint32_t* d_s0 = reinterpret_cast<uint32_t*>(base);
+    uint32_t* d_s1 = d_s0 + npix_out;
+    uint8_t* d_w0 = reinterpret_cast<uint8_t*>(d_s1 + npix_out);
+    uint8_t* d_w1 = d_w0 + npix_out;
+    uint8_t* d_in = d_w1 + npix_out;
+    uint8_t* d_out = d_in + in_b;
+    VK_HIP(ctx, hipMemcpyAsync(d_s0, src0, lut_b, hipMemcpyHostToDevice, ctx->stream));
+    if (sum_rc) {
+        VK_HIP(ctx, hipMemcpyAsync(d_s1, src1, lut_b, hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(d_w0, w0, npix_out, hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(d_w1, w1, npix_out, hipMemcpyHostToDevice, ctx->stream));
+    }
+    VK_HIP(ctx, hipMemcpyAsync(d_in, img_in, in_b, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(vk_remap_kernel, dim3(nimg), dim3(256), 0, ctx->stream, d_in, npix_in, npix_out, d_s0, d_s1,
+                       d_w0, d_w1, sum_rc, d_out);
+    VK_HIP(ctx, hipGetLastError());
+    VK_HIP(ctx, hipMemcpyAsync(img_out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VK_OK;
 }
 

@@ -127,3 +127,37 @@ def test_batched_pipeline_writes_reference_named_pngs(tmp_path):
     # a second run skips what exists (checkpoint/resume by file existence, image.py:857-859)
     again = pipeline.fastqs_to_images(files[:-1], tmp_path / "images", k=7, mapping_code="varKode")
     assert again == {}
+
+
+def test_cli_image_on_an_intermediate_folder(tmp_path):
+    """`python -m varkoder_amd image INT -k 7 -p cgr -o OUT -f stats.csv -t`: same flags as the
+    reference CLI (cli.py:69-166), entering at step D on a folder of split FASTQs."""
+    import pandas as pd
+    from PIL import Image
+    from varkoder_amd import cli
+    split = tmp_path / "int" / "split_fastqs"
+    split.mkdir(parents=True)
+    datas = {}
+    for name, s, reads in (("tax1_A@00000150K.fq", 60, 1000), ("tax1_A@00000075K.fq", 61, 500),
+                           ("tax2_B@00000150K.fq.gz", 62, 1000)):
+        datas[name] = _write_fastq(split / name, s, reads, gz=name.endswith(".gz"))
+    (tmp_path / "labels.csv").write_text("sample,labels\ntax1_A,genus:A;family:F\ntax2_B,genus:B\n")
+    out, stats = tmp_path / "images", tmp_path / "stats.csv"
+    cli.main(["image", str(tmp_path / "int"), "-k", "7", "-p", "cgr", "-o", str(out), "-f", str(stats), "-t",
+              "--labels-csv", str(tmp_path / "labels.csv"), "-n", "2"])
+    for name, data in datas.items():
+        stem = name.split(".fq")[0]
+        im = Image.open(out / f"{stem}+cgr+k7.png")
+        want, _, st = oracle.fastq_to_image(data, 7, pixel_lut(7, "cgr"), 128 * 128)
+        assert st == 0 and np.array_equal(np.array(im).ravel(), want)
+        assert im.info["varkoderMapping"] == "cgr"
+    assert Image.open(out / "tax1_A@00000150K+cgr+k7.png").info["varkoderKeywords"] == "genus:A;family:F"
+    df = pd.read_csv(stats)
+    assert list(df["sample"]) == ["tax1_A", "tax2_B"]
+    assert {"7mer_counting_time", "k7_img_time"} <= set(df.columns)
+    lt = pd.read_csv(out / "labels.csv")
+    assert list(lt.columns) == ["sample", "labels", "possible_low_quality"]
+    with pytest.raises(Exception, match="Output directory exists"):
+        cli.main(["image", str(tmp_path / "int"), "-o", str(out), "-f", str(stats)])
+    with pytest.raises(ValueError, match="between 5 and 9"):
+        cli.main(["image", str(tmp_path / "int"), "-k", "4", "-o", str(tmp_path / "o2")])

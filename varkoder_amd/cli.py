@@ -1,0 +1,130 @@
+"""`python -m varkoder_amd image ...`: steps D+E of `varKoder image` on the GPU.
+
+Same flags as the reference's `image` sub-command (varKoder/cli.py:69-166).  Steps B/C of
+the reference (fastp cleaning, reformat.sh subsampling) are external CPU tools outside this
+path: run the reference once with `-X/--no-image -i INT` (clean + split only, cli.py:155-160)
+and point this command at INT (or at its `split_fastqs/` folder).  Every file
+`<sample>@<bp>K.fq[.gz]` becomes `<outdir>/<sample>@<bp>K+<mapping>+k<k>.png` with the
+reference's metadata; `stats.csv` (and `labels.csv` with -t) are written like
+process_stats does (commands/image.py:1144-1185).  With torchrun, ranks shard the files.
+"""
+import argparse
+import math
+import shutil
+import sys
+from collections import OrderedDict, defaultdict
+from pathlib import Path
+
+from . import __version__
+from .config import (DEFAULT_KMER_MAPPING, DEFAULT_KMER_SIZE, KMER_MAX, KMER_MIN, LABELS_SEP, MAPPING_CHOICES,
+                     QUAL_THRESH, SAMPLE_BP_SEP)
+from .image import eprint
+
+
+def setup_parser():
+    main = argparse.ArgumentParser(prog="varkoder_amd", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                   description="MI355X-native k-mer counting and varKode/rfCGR imaging")
+    sub = main.add_subparsers(required=True, dest="command")
+    p = sub.add_parser("image", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                       help="count k-mers and write images for already cleaned + split reads")
+    p.add_argument("input", help="intermediate folder of a `varKoder image -X -i` run (or its split_fastqs/)")
+    p.add_argument("-R", "--seed", type=int, help="random seed (accepted for parity; nothing here is random)")
+    p.add_argument("-x", "--overwrite", action="store_true", help="overwrite existing results.")
+    p.add_argument("-v", "--verbose", action="store_true", default=False)
+    p.add_argument("-vv", "--version", action="version", version=f"%(prog)s {__version__}")
+    p.add_argument("-k", "--kmer-size", type=int, default=DEFAULT_KMER_SIZE, help="size of kmers to count (5-9)")
+    p.add_argument("-p", "--kmer-mapping", type=str, default=DEFAULT_KMER_MAPPING, choices=MAPPING_CHOICES)
+    p.add_argument("-n", "--n-threads", type=int, default=1, help="host threads for file reading / PNG writing")
+    p.add_argument("-c", "--cpus-per-thread", type=int, default=1, help="accepted for parity, unused")
+    p.add_argument("-o", "--outdir", default="images", help="path to folder where to write final images.")
+    p.add_argument("-f", "--stats-file", default="stats.csv", help="path to file where sample statistics will be saved.")
+    p.add_argument("-i", "--int-folder", help="accepted for parity (the input IS the intermediate folder)")
+    p.add_argument("-m", "--min-bp", type=str, default="500K", help="applied upstream by the split step; accepted for parity")
+    p.add_argument("-M", "--max-bp", default="200M", help="applied upstream by the split step; accepted for parity")
+    p.add_argument("-t", "--label-table", action="store_true", help="also write labels.csv")
+    p.add_argument("-a", "--no-adapter", action="store_true", help="upstream (fastp) option; accepted for parity")
+    p.add_argument("-D", "--no-deduplicate", action="store_true", help="upstream (fastp) option; accepted for parity")
+    p.add_argument("-r", "--no-merge", action="store_true", help="upstream (fastp) option; accepted for parity")
+    p.add_argument("-X", "--no-image", action="store_true", help="nothing to do here without images")
+    p.add_argument("-T", "--trim-bp", default="10,10", help="upstream (fastp) option; accepted for parity")
+    p.add_argument("--labels-csv", help="optional CSV `sample,labels` (labels separated by ';')")
+    return main
+
+
+def read_labels(path):
+    import pandas as pd
+    if not path:
+        return {}
+    df = pd.read_csv(path, dtype=str).fillna("")
+    return {r["sample"]: [x for x in r["labels"].split(LABELS_SEP) if x] for _, r in df.iterrows()}
+
+
+def run_image(args):
+    import pandas as pd
+    from .pipeline import fastqs_to_images
+    from .shard import gather_stats, world_info
+    if args.kmer_size not in range(KMER_MIN, KMER_MAX + 1):
+        raise ValueError("kmer size must be between 5 and 9")               # image.py:1209-1210
+    rank, world, local_rank = world_info()
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)        # control plane only
+    outdir = Path(args.outdir)
+    if rank == 0:
+        if not args.overwrite and outdir.exists():                          # image.py:1219-1223
+            raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
+        if outdir.is_dir():
+            shutil.rmtree(outdir)
+        outdir.mkdir(parents=True)
+    if world > 1:
+        dist.barrier()
+    src = Path(args.input)
+    if (src / "split_fastqs").is_dir():
+        src = src / "split_fastqs"
+    files = sorted(f for f in src.iterdir() if SAMPLE_BP_SEP in f.name and f.is_file())
+    if not files:
+        raise Exception("No files found in input. Please check.")            # image.py:1309-1310
+    samples = sorted({f.name.split(SAMPLE_BP_SEP)[0] for f in files})
+    levels = math.floor(math.log(len(samples) / 1000, 16)) if samples else 0  # image.py:1246
+    levels = max(levels, 0)
+    labels = read_labels(args.labels_csv)
+    eprint("varkoder_amd")
+    eprint("Kmer size:", str(args.kmer_size))
+    eprint("Counting kmers and creating images for", len(files), "files of", len(samples), "samples")
+    if args.no_image:
+        return
+    per_file = fastqs_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping, labels=labels,
+                                overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
+                                world=world, io_threads=max(1, args.n_threads) * 4, verbose=args.verbose)
+    # fold the per-file stats into per-sample stats like run_clean2img does (image.py:1057-1125)
+    mine = defaultdict(OrderedDict)
+    ck, ik = f"{args.kmer_size}mer_counting_time", f"k{args.kmer_size}_img_time"
+    for key, st in per_file.items():
+        s = mine[key.split(SAMPLE_BP_SEP)[0]]
+        for name in (ck, ik):
+            s[name] = s.get(name, 0) + st.get(name, 0)
+        if "failed_step" in st:
+            s["failed_step"] = st["failed_step"]
+    merged = gather_stats(mine)
+    if rank == 0:
+        rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
+        pd.DataFrame(rows).to_csv(args.stats_file, index=False)
+        if args.label_table:
+            lt = pd.DataFrame({"sample": samples,
+                               "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
+                               "possible_low_quality": [0 > QUAL_THRESH for _ in samples]})
+            lt.to_csv(outdir / "labels.csv", index=False)
+        eprint("All images done, saved in", str(outdir))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = setup_parser().parse_args(argv)
+    if args.command == "image":
+        run_image(args)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

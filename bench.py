@@ -81,10 +81,40 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(one, range(nsamp)))
     dt = time.perf_counter() - t0
-    return {"value": nsamp * bases_per_sample / dt / 1e9, "unit": "Gbases/s", "cores": cores,
-            "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9,
-            "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
-                      f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
+    out = {"value": nsamp * bases_per_sample / dt / 1e9, "unit": "Gbases/s", "cores": cores,
+           "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9,
+           "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
+                     f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
+    ref = dsk_reference(bufs[0], args, cores)
+    if ref:
+        out["dsk"] = ref
+    return out
+
+
+def dsk_reference(buf, args, cores):
+    """If GATB dsk is on PATH (it is not in the build image), time the reference's exact
+    invocation (varKoder/commands/image.py:771-790, :875-886) on one sample of the workload."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not (shutil.which("dsk") and shutil.which("dsk2ascii")):
+        return None
+    with tempfile.TemporaryDirectory(prefix="vkbench_") as tmp:
+        fq = os.path.join(tmp, "s@00150000K.fq")
+        buf.tofile(fq)
+        res = {}
+        for nc in (1, cores):
+            h5 = os.path.join(tmp, f"s_{nc}.h5")
+            t0 = time.perf_counter()
+            subprocess.run(["dsk", "-nb-cores", str(nc), "-kmer-size", str(args.k), "-abundance-min", "1",
+                            "-abundance-min-threshold", "1", "-max-memory", "1000", "-file", fq, "-out-tmp", tmp,
+                            "-out", h5], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            subprocess.run(["dsk2ascii", "-c", "-file", h5, "-nb-cores", str(nc), "-out",
+                            os.path.join(tmp, "dsk.txt"), "-verbose", "0"], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            res[f"gbases_per_s_{nc}_cores"] = args.reads * args.readlen / (time.perf_counter() - t0) / 1e9
+        res["kind"] = "reference (dsk + dsk2ascii, one sample)"
+        return res
 
 
 def main():

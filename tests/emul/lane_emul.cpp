@@ -94,7 +94,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     carry_c = lb[lane].C[3];
                     vkl::ok_mask<K>(badh, bad, ok);
                     if (it == 0 && lane == 0) ok[0] = ok[1] = ok[2] = ok[3] = 0;
-                    vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; });
+                    vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; }, [] {});
                 }
                 pph += total;
             }

@@ -151,3 +151,38 @@ def test_full_size_samples_match_oracle(engines, k, mapping):
     cs = torch.cat([torch.zeros((reads, 1), dtype=cs.dtype, device=cs.device), cs], dim=1)
     clean = ((cs[:, k:] - cs[:, :-k]) == 0).sum().item()
     assert clean == nwins[0]
+
+
+@pytest.mark.parametrize("k", (8, 9))
+def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
+    """k = 8, 9 bucket windows through LDS queues into per-part streams.  A low-complexity sample
+    sends (almost) every window to ONE part: its queue and its bucket overflow, and the overflow
+    must still be counted exactly (global-atomic fallbacks)."""
+    from fastq_cases import rec
+    rng = np.random.default_rng(k)
+    reads = []
+    for i in range(30000):
+        r = rng.random()
+        if r < 0.7:
+            seq = "A" * 150
+        elif r < 0.85:
+            seq = "ACACACACAC" * 15
+        else:
+            seq = "".join(rng.choice(list("ACGT"), size=150))
+        reads.append(rec(f"r{i}", seq))
+    fq = b"".join(reads)
+    eng = engines(k)
+    want, nwin, st = oracle.count_fastq(fq, k)
+    assert st == 0
+    dev, offs, lens = eng.upload([fq, fq[: len(fq) // 2 - (len(fq) // 2) % 1 ]])
+    # second sample: cut at a record boundary
+    cut = fq.rfind(b"\n@", 0, len(fq) // 2) + 1
+    dev, offs, lens = eng.upload([fq, fq[:cut]])
+    want2 = oracle.count_fastq(fq[:cut], k)[0]
+    for parts in (1, 4):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got = hist.cpu().numpy().view(np.uint32)
+        assert int(got[0].sum(dtype=np.uint64)) == nwin
+        assert np.array_equal(got[0], want), parts
+        assert np.array_equal(got[1], want2), parts

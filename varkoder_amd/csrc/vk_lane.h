@@ -261,10 +261,11 @@ VKL_FN void ok_mask(uint32_t badh, const uint32_t bad[4], uint32_t ok[4]) {
 }
 
 // Window loop: for every position p with its OK bit set, emit(code << 2) where code is
+// (after_group() runs after each 16-position group)
 // the K-mer ending at p, read from the code string [ch | C[0..3]] (ch = codes of the 16
 // positions before the block).  First base most significant.
-template <int K, typename Emit>
-VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit emit) {
+template <int K, typename Emit, typename Hook>
+VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit emit, Hook after_group) {
     // Codes are packed with the EARLIEST position in the LOWEST bits, so a raw bit-field is
     // the k-mer with its first base least significant; the histogram convention wants the
     // first base most significant.  The kernel therefore counts into a bit-reversed index
@@ -314,6 +315,7 @@ VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit
                 }
             }
         }
+        after_group();  // 16 positions of every lane done (the bucket path drains its queues here)
     }
 }
 

@@ -167,166 +167,355 @@ __device__ __forceinline__ uint4 load_granule_s(const uint8_t* sbase, long long 
     return load_granule(sbase, static_cast<uint64_t>(off), lim);
 }
 
-template <int K, int LOG_PARTS>
-__global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
-    const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
-    const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
-    constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t HPARTS = 1u << LOG_PARTS;
-    constexpr uint32_t BINS = NCODE >> LOG_PARTS;
-    constexpr uint32_t PSHIFT = 2 * K - LOG_PARTS;
-    static_assert(BINS <= kMaxBins, "LDS histogram too large");
+// Byte range [w0, w1) of workgroup `part` of `parts`, wave `wave` of kWaves (64-byte blocks).
+struct WaveRange {
+    uint64_t w0, w1;
+    bool empty;
+};
 
-    // The LDS histogram is indexed by the RAW packed field (first base least
-    // significant, see vk_lane.h); the flush un-reverses to the ABI's code order.
-    __shared__ uint32_t hist[BINS];
-    __shared__ uint4 stage[kWaves][kPiece / 16];
-    __shared__ uint4 below[66];  // below[q] = bits [0, 2q) of a 128-bit string
-    __shared__ uint4 above[66];  // above[q] = ~below[q]
-
-    // block -> (unit = (sample, part), histogram part); the HPARTS siblings of a
-    // unit get block ids that differ by multiples of 8, i.e. share an XCD's L2.
-    const uint32_t bid = blockIdx.x;
-    const uint32_t grp = bid / (8u * HPARTS);
-    const uint32_t rem = bid % (8u * HPARTS);
-    const uint32_t hp = rem / 8u;
-    const uint32_t unit = grp * 8u + (rem % 8u);
-    if (unit >= nsamples * parts) return;  // whole workgroup, before any barrier
-    const uint32_t s = unit / parts;
-    const uint32_t part = unit % parts;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
-    if (tid < 66) {
-        vkl::Mask128 m = vkl::ones_below(static_cast<uint32_t>(tid));
-        below[tid] = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
-        above[tid] = make_uint4(~m.w[0], ~m.w[1], ~m.w[2], ~m.w[3]);
-    }
-    __syncthreads();
-
-    const uint8_t* sbase = fastq + offs[s];
-    const uint64_t len = lens[s];
+__device__ __forceinline__ WaveRange wave_range(uint64_t len, uint32_t parts, uint32_t part, int wave) {
     const uint64_t nblk = (len + 63) >> 6;
     const uint64_t bwg = (nblk + parts - 1) / parts;
     const uint64_t bw = (bwg + kWaves - 1) / kWaves;
     uint64_t blk0 = static_cast<uint64_t>(part) * bwg + static_cast<uint64_t>(wave) * bw;
     uint64_t blk1 = static_cast<uint64_t>(part) * bwg + umin64(static_cast<uint64_t>(wave + 1) * bw, bwg);
     if (blk1 > nblk) blk1 = nblk;
-    const bool empty = blk0 >= blk1;
-    const uint64_t w0 = blk0 << 6;
-    const uint64_t w1 = empty ? w0 : umin64(blk1 << 6, len);
+    WaveRange r;
+    r.empty = blk0 >= blk1;
+    r.w0 = blk0 << 6;
+    r.w1 = r.empty ? r.w0 : umin64(blk1 << 6, len);
+    return r;
+}
 
-    uint32_t ph_start = 0, ph_end = 0;
-    if (!empty) {
-        uint64_t* slot = reinterpret_cast<uint64_t*>(&stage[wave][0]);
-        const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, slot, lane) : 0u;
-        ph_start = ph0;
+// One wavefront streams the FASTQ bytes [w0, w1) of a sample and calls emit(raw_field << 2)
+// for every countable K-mer window (raw field: first base least significant, vk_lane.h);
+// after_group() runs after every 16 positions.  `st` is the wave's private 4 KiB LDS slot,
+// below/above the shared mask tables.  Returns the line phase at w0 and at w1.
+template <int K, typename Emit, typename Hook>
+__device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
+                                            uint64_t w1, uint4* st, const uint4* below, const uint4* above,
+                                            int lane, Emit emit, Hook after_group, uint32_t& ph_start,
+                                            uint32_t& ph_end) {
+    const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(st), lane) : 0u;
+    ph_start = ph0;
 
-        // Pieces start one 64-byte block BEFORE the range: lane 0 of piece 0 (the
-        // "pre-block") only supplies the k-1 bases of context and its windows are
-        // not counted.  From then on lane 0 takes its context from lane 63 of the
-        // previous piece.
-        const long long o0 = static_cast<long long>(w0) - 64;
-        const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
-        uint4 r0, r1, r2, r3;
-        // A piece that lies wholly inside [0, w1) (all but the first and last of a range) is
-        // loaded with four unguarded 16-byte loads off one address; edge pieces zero-fill.
-        auto load_piece = [&](uint64_t piece) {
-            const long long pb = o0 + static_cast<long long>(piece) * kPiece;
-            if (pb >= 0 && static_cast<uint64_t>(pb) + kPiece <= w1) {  // wave-uniform
-                const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + lane;
-                r0 = g[0];
-                r1 = g[64];
-                r2 = g[128];
-                r3 = g[192];
-            } else {
-                const long long p = pb + static_cast<long long>(lane) * 16;
-                r0 = load_granule_s(sbase, p, w1);
-                r1 = load_granule_s(sbase, p + 1024, w1);
-                r2 = load_granule_s(sbase, p + 2048, w1);
-                r3 = load_granule_s(sbase, p + 3072, w1);
-            }
-        };
-        load_piece(0);
-        uint32_t carry_c = 0u, carry_bad = 0x55555555u;
-        uint32_t pph = 0;  // line phase at the start of the current piece
-        auto tbl_below = [&](uint32_t q) {
-            uint4 v = below[q];
-            vkl::Mask128 m;
-            m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
-            return m;
-        };
-        auto tbl_above = [&](uint32_t q) {
-            uint4 v = above[q];
-            vkl::Mask128 m;
-            m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
-            return m;
-        };
-        auto emit = [&](uint32_t a4) {
-            // a4 = raw field << 2 = byte offset into the raw-indexed histogram
-            if (HPARTS == 1 || (a4 >> (PSHIFT + 2)) == hp)
-                atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + (a4 & ((BINS - 1u) << 2))), 1u);
-        };
-        for (uint64_t it = 0; it < npieces; ++it) {
-            // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
-            uint4* st = &stage[wave][0];
-            wave_lds_fence();
-            st[lane] = r0;
-            st[64 + lane] = r1;
-            st[128 + lane] = r2;
-            st[192 + lane] = r3;
-            wave_lds_fence();
-            uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
-            wave_lds_fence();
-            if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
-            const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            vkl::LaneBits lb;
-            const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
-
-            // newline prefix over the wave -> line phase at the start of each lane's block
-            const uint32_t incl = wave_inclusive_sum(c);
-            const uint32_t total = lane_bcast(incl, 63);
-            if (it == 0) pph = ph0 - lane_bcast(c, 0);  // the pre-block's newlines precede w0
-            const uint32_t lph = (pph + incl - c) & 3u;
-
-            vkl::Mask128 seq;
-            if (__any(c > 3u)) seq = vkl::seq_mask_general(lb.NL, lph);
-            else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above);
-            uint32_t bad[4], ok[4];
-            vkl::bad_mask(lb, seq, bad);
-
-            const uint32_t badh = wave_prev_lane(bad[3], carry_bad);
-            const uint32_t ch = wave_prev_lane(lb.C[3], carry_c);
-            carry_bad = lane_bcast(bad[3], 63);
-            carry_c = lane_bcast(lb.C[3], 63);
-
-            vkl::ok_mask<K>(badh, bad, ok);
-            if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
-            vkl::windows<K>(ch, lb.C, ok, emit);
-            pph += total;
+    // Pieces start one 64-byte block BEFORE the range: lane 0 of piece 0 (the "pre-block")
+    // only supplies the k-1 bases of context and its windows are not counted.  From then on
+    // lane 0 takes its context from lane 63 of the previous piece.
+    const long long o0 = static_cast<long long>(w0) - 64;
+    const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
+    uint4 r0, r1, r2, r3;
+    // A piece that lies wholly inside [0, w1) (all but the first and last of a range) is
+    // loaded with four unguarded 16-byte loads off one address; edge pieces zero-fill.
+    auto load_piece = [&](uint64_t piece) {
+        const long long pb = o0 + static_cast<long long>(piece) * kPiece;
+        if (pb >= 0 && static_cast<uint64_t>(pb) + kPiece <= w1) {  // wave-uniform
+            const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + lane;
+            r0 = g[0];
+            r1 = g[64];
+            r2 = g[128];
+            r3 = g[192];
+        } else {
+            const long long p = pb + static_cast<long long>(lane) * 16;
+            r0 = load_granule_s(sbase, p, w1);
+            r1 = load_granule_s(sbase, p + 1024, w1);
+            r2 = load_granule_s(sbase, p + 2048, w1);
+            r3 = load_granule_s(sbase, p + 3072, w1);
         }
-        ph_end = pph & 3u;
+    };
+    load_piece(0);
+    uint32_t carry_c = 0u, carry_bad = 0x55555555u;
+    uint32_t pph = 0;  // line phase at the start of the current piece
+    auto tbl_below = [&](uint32_t q) {
+        uint4 v = below[q];
+        vkl::Mask128 m;
+        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+        return m;
+    };
+    auto tbl_above = [&](uint32_t q) {
+        uint4 v = above[q];
+        vkl::Mask128 m;
+        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+        return m;
+    };
+    for (uint64_t it = 0; it < npieces; ++it) {
+        // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
+        wave_lds_fence();
+        st[lane] = r0;
+        st[64 + lane] = r1;
+        st[128 + lane] = r2;
+        st[192 + lane] = r3;
+        wave_lds_fence();
+        uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
+        wave_lds_fence();
+        if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
+        const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        vkl::LaneBits lb;
+        const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
+
+        // newline prefix over the wave -> line phase at the start of each lane's block
+        const uint32_t incl = wave_inclusive_sum(c);
+        const uint32_t total = lane_bcast(incl, 63);
+        if (it == 0) pph = ph0 - lane_bcast(c, 0);  // the pre-block's newlines precede w0
+        const uint32_t lph = (pph + incl - c) & 3u;
+
+        vkl::Mask128 seq;
+        if (__any(c > 3u)) seq = vkl::seq_mask_general(lb.NL, lph);
+        else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above);
+        uint32_t bad[4], ok[4];
+        vkl::bad_mask(lb, seq, bad);
+
+        const uint32_t badh = wave_prev_lane(bad[3], carry_bad);
+        const uint32_t ch = wave_prev_lane(lb.C[3], carry_c);
+        carry_bad = lane_bcast(bad[3], 63);
+        carry_c = lane_bcast(lb.C[3], 63);
+
+        vkl::ok_mask<K>(badh, bad, ok);
+        if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+        vkl::windows<K>(ch, lb.C, ok, emit, after_group);
+        pph += total;
     }
-    if (hp == 0 && lane == 0) {
-        uint32_t idx = (s * parts + part) * kWaves + wave;
-        wavephase[idx] = empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+    ph_end = pph & 3u;
+}
+
+__device__ __forceinline__ void fill_mask_tables(uint4* below, uint4* above, int tid) {
+    if (tid < 66) {
+        vkl::Mask128 m = vkl::ones_below(static_cast<uint32_t>(tid));
+        below[tid] = make_uint4(m.w[0], m.w[1], m.w[2], m.w[3]);
+        above[tid] = make_uint4(~m.w[0], ~m.w[1], ~m.w[2], ~m.w[3]);
     }
+}
+
+// K <= 7: the whole 4^K u32 histogram lives in LDS.
+template <int K>
+__global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
+    const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+    const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    static_assert(NCODE <= kMaxBins, "LDS histogram too large");
+
+    // The LDS histogram is indexed by the RAW packed field (first base least
+    // significant, see vk_lane.h); the flush un-reverses to the ABI's code order.
+    __shared__ uint32_t hist[NCODE];
+    __shared__ uint4 stage[kWaves][kPiece / 16];
+    __shared__ uint4 below[66];  // below[q] = bits [0, 2q) of a 128-bit string
+    __shared__ uint4 above[66];  // above[q] = ~below[q]
+
+    const uint32_t unit = blockIdx.x;
+    const uint32_t s = unit / parts;
+    const uint32_t part = unit % parts;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    for (uint32_t i = tid; i < NCODE; i += kCountThreads) hist[i] = 0u;
+    fill_mask_tables(below, above, tid);
+    __syncthreads();
+
+    const uint8_t* sbase = fastq + offs[s];
+    const uint64_t len = lens[s];
+    const WaveRange wr = wave_range(len, parts, part, wave);
+    uint32_t ph_start = 0, ph_end = 0;
+    if (!wr.empty) {
+        auto emit = [&](uint32_t a4) {  // a4 = raw field << 2 = byte offset into the histogram
+            atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + a4), 1u);
+        };
+        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, [] {}, ph_start, ph_end);
+    }
+    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
-    for (uint32_t i = tid; i < BINS; i += kCountThreads) {
+    for (uint32_t i = tid; i < NCODE; i += kCountThreads) {
         const uint32_t v = hist[i];
-        const uint32_t code = pair_reverse((hp << PSHIFT) | i, K);  // ABI order: first base most significant
+        const uint32_t code = pair_reverse(i, K);  // ABI order: first base most significant
         if (atomic_flush) {
             if (v) atomicAdd(&out[code], v);
         } else {
             out[code] = v;
         }
+    }
+}
+
+// ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
+// 4^K u32 counters do not fit LDS.  Pass A streams the FASTQ exactly like vk_count_kernel but
+// appends every window's low 14 bits to one of PARTS = 4^(K-7) wave-private LDS queues chosen by
+// the window's top bits, and drains full queues as 128-byte blocks into per-(sample, part)
+// bucket streams in HBM (block runs reserved with one global atomic per 32 blocks).  Pass B
+// gives every (sample, part) one workgroup that replays its stream into a 16384-bin LDS
+// histogram.  Entries that cannot be queued or whose bucket is full are counted with global
+// atomics on the spot: slower, still exact.
+constexpr uint32_t kBlockEntries = 64;   // u16 entries per 128-byte bucket block
+constexpr uint32_t kRunBlocks = 32;      // blocks reserved per global atomic
+constexpr uint32_t kQueueEntries = 2048; // u16 entries of queue space per wave (all parts)
+
+struct BucketParams {
+    uint32_t* cursors;   // [nsamples][PARTS] next free block of each bucket stream
+    uint32_t* buckets;   // [nsamples][PARTS][cap_blocks * 32] dwords
+    uint32_t cap_blocks; // multiple of kRunBlocks
+};
+
+template <int K>
+__global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
+    const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+    const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t PARTS = NCODE >> 14;
+    constexpr uint32_t QCAP = kQueueEntries / PARTS;  // entries per (wave, part) queue
+    constexpr uint32_t FLUSH_AT = QCAP / 2;
+    static_assert(QCAP >= 2 * kBlockEntries, "queue must hold two blocks");
+
+    __shared__ uint4 stage[kWaves][kPiece / 16];
+    __shared__ uint4 below[66];
+    __shared__ uint4 above[66];
+    __shared__ uint32_t qbuf[kWaves][kQueueEntries / 2];  // u16 entries, two per dword
+    __shared__ uint32_t qcnt[kWaves][16];
+    __shared__ uint32_t runbase[kWaves][16];
+    __shared__ uint32_t runleft[kWaves][16];
+
+    const uint32_t unit = blockIdx.x;
+    const uint32_t s = unit / parts;
+    const uint32_t part = unit % parts;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    fill_mask_tables(below, above, tid);
+    if (lane < 16) {
+        qcnt[wave][lane] = 0u;
+        runbase[wave][lane] = 0u;
+        runleft[wave][lane] = 0u;
+    }
+    __syncthreads();
+
+    const uint8_t* sbase = fastq + offs[s];
+    const uint64_t len = lens[s];
+    const WaveRange wr = wave_range(len, parts, part, wave);
+    uint32_t* hist_s = hist_out + static_cast<uint64_t>(s) * NCODE;
+    uint16_t* q16 = reinterpret_cast<uint16_t*>(&qbuf[wave][0]);
+
+    // write `nb` blocks of 0xFFFF padding at block index `base` of bucket (s, q)
+    auto pad_blocks = [&](uint32_t q, uint32_t base, uint32_t nb) {
+        uint32_t* dst = bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) * bp.cap_blocks * 32u +
+                        static_cast<uint64_t>(base) * 32u;
+        for (uint32_t dw = lane; dw < nb * 32u; dw += 64) dst[dw] = 0xFFFFFFFFu;
+    };
+    // drain the first `nb` blocks of queue q (wave-uniform arguments)
+    auto drain = [&](uint32_t q, uint32_t n, uint32_t nb) {
+        uint32_t base = runbase[wave][q], left = runleft[wave][q];
+        bool have = true;
+        if (left < nb) {
+            if (left) pad_blocks(q, base, left);  // the rest of the old run stays padding
+            uint32_t nbase = 0;
+            if (lane == 0) nbase = atomicAdd(&bp.cursors[s * PARTS + q], kRunBlocks);
+            nbase = lane_bcast(nbase, 0);
+            have = nbase + kRunBlocks <= bp.cap_blocks;
+            base = nbase;
+            left = have ? kRunBlocks : 0u;
+        }
+        const uint32_t* src = &qbuf[wave][q * (QCAP / 2)];
+        if (have) {
+            uint32_t* dst = bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) * bp.cap_blocks * 32u +
+                            static_cast<uint64_t>(base) * 32u;
+            for (uint32_t dw = lane; dw < nb * 32u; dw += 64) dst[dw] = src[dw];
+            base += nb;
+            left -= nb;
+        } else {  // bucket full: count these entries directly (exact, slow)
+            for (uint32_t e = lane; e < nb * kBlockEntries; e += 64) {
+                const uint32_t loc = q16[q * QCAP + e];
+                if (loc != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << 14) | loc, K)], 1u);
+            }
+        }
+        // move the remainder (< one block) to the front
+        const uint32_t done = nb * kBlockEntries;
+        const uint32_t rem = n > done ? n - done : 0u;
+        wave_lds_fence();
+        uint32_t keep = 0;
+        if (static_cast<uint32_t>(lane) < rem) keep = q16[q * QCAP + done + lane];
+        wave_lds_fence();
+        if (static_cast<uint32_t>(lane) < rem) q16[q * QCAP + lane] = static_cast<uint16_t>(keep);
+        if (lane == 0) {
+            qcnt[wave][q] = rem;
+            runbase[wave][q] = base;
+            runleft[wave][q] = left;
+        }
+        wave_lds_fence();
+    };
+
+    uint32_t ph_start = 0, ph_end = 0;
+    if (!wr.empty) {
+        auto emit = [&](uint32_t a4) {
+            const uint32_t raw = a4 >> 2;
+            const uint32_t q = raw >> 14, loc = raw & 0x3FFFu;
+            const uint32_t idx = atomicAdd(&qcnt[wave][q], 1u);  // returning LDS atomic
+            if (idx < QCAP) q16[q * QCAP + idx] = static_cast<uint16_t>(loc);
+            else atomicAdd(&hist_s[pair_reverse(raw, K)], 1u);   // queue full: exact slow path
+        };
+        auto after_group = [&]() {
+            wave_lds_fence();
+            const uint32_t cnt = static_cast<uint32_t>(lane) < PARTS ? qcnt[wave][lane] : 0u;
+            unsigned long long m = __ballot(cnt >= FLUSH_AT);
+            while (m) {
+                const int q = __builtin_ctzll(m);
+                m &= m - 1;
+                uint32_t n = lane_bcast(cnt, q);
+                if (n > QCAP) n = QCAP;
+                drain(static_cast<uint32_t>(q), n, n / kBlockEntries);
+            }
+        };
+        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, after_group, ph_start,
+                       ph_end);
+        // final drain: pad the last partial block of every queue, then the rest of every run
+        wave_lds_fence();
+        for (uint32_t q = 0; q < PARTS; ++q) {
+            uint32_t n = qcnt[wave][q];
+            if (n > QCAP) n = QCAP;
+            const uint32_t nb = (n + kBlockEntries - 1) / kBlockEntries;
+            for (uint32_t e = n + lane; e < nb * kBlockEntries; e += 64) q16[q * QCAP + e] = 0xFFFFu;
+            wave_lds_fence();
+            if (nb) drain(q, n, nb);
+            const uint32_t left = runleft[wave][q];
+            if (left) pad_blocks(q, runbase[wave][q], left);
+        }
+    }
+    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+}
+
+// Pass B: one workgroup per (sample, part) replays the bucket stream into LDS and adds the
+// 16384 counters to the histogram (which already holds pass A's direct counts).
+template <int K>
+__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp,
+                                                                         uint32_t* __restrict__ hist_out) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t PARTS = NCODE >> 14;
+    __shared__ uint32_t hist[16384];
+    const uint32_t s = blockIdx.x / PARTS, q = blockIdx.x % PARTS;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 16384; i += kCountThreads) hist[i] = 0u;
+    __syncthreads();
+    uint32_t nblk = bp.cursors[s * PARTS + q];
+    if (nblk > bp.cap_blocks) nblk = bp.cap_blocks;
+    const uint4* src = reinterpret_cast<const uint4*>(bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) *
+                                                                       bp.cap_blocks * 32u);
+    const uint64_t n16 = static_cast<uint64_t>(nblk) * 8u;  // 16-byte groups
+    for (uint64_t i = tid; i < n16; i += kCountThreads) {
+        const uint4 v = src[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
+            if (lo != 0xFFFFu) atomicAdd(&hist[lo], 1u);
+            if (hi != 0xFFFFu) atomicAdd(&hist[hi], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
+    for (uint32_t i = tid; i < 16384; i += kCountThreads) {
+        const uint32_t v = hist[i];
+        if (v) out[pair_reverse((q << 14) | i, K)] += v;  // this workgroup owns these codes now
     }
 }
 
@@ -653,6 +842,9 @@ struct vk_ctx {
     size_t wavephase_cap = 0;
     uint32_t* d_scratch = nullptr;
     size_t scratch_cap = 0;
+    uint32_t* d_spill = nullptr;  // k >= 8: bucket cursors + bucket streams
+    size_t spill_cap = 0;
+    size_t spill_budget = 96ull << 30;  // bytes of HBM the spill path may use at a time
     // host-call staging
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
@@ -712,18 +904,60 @@ uint32_t npad_of(uint32_t npix) {
     return p;
 }
 
-template <int K, int LP>
+template <int K>
 int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
-                 uint32_t nsamples, uint32_t parts, uint32_t* d_hist, int atomic_flush) {
-    constexpr uint32_t HP = 1u << LP;
-    uint32_t units = nsamples * parts;
-    uint32_t grid = ((units + 7u) / 8u) * 8u * HP;
+                 uint32_t nsamples, uint32_t parts, uint64_t /*maxlen*/, uint32_t* d_hist) {
+    const uint32_t grid = nsamples * parts;
+    const int atomic_flush = parts > 1 ? 1 : 0;
+    if (atomic_flush)
+        VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * (1u << (2 * K)) * sizeof(uint32_t),
+                                   ctx->stream));
     ctx->last_grid = grid;
     ctx->last_block = kCountThreads;
-    ctx->last_lds = ((1u << (2 * K)) >> LP) * 4u + kWaves * kPiece + 2 * 66 * 16;
-    hipLaunchKernelGGL((vk_count_kernel<K, LP>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
+    ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * kPiece + 2 * 66 * 16;
+    hipLaunchKernelGGL((vk_count_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
                        d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
     VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+// k = 8, 9: bucket pass + replay pass, in sub-batches that fit the spill budget.
+template <int K>
+int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
+                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t PARTS = NCODE >> 14;
+    // windows <= bytes/2; a uniform sample sends ~0.45*bytes/PARTS entries to each part.  Room for
+    // bytes/PARTS entries (2.2x) plus the run each wave may leave unfinished.
+    uint64_t cap = maxlen / PARTS / kBlockEntries + 1 + static_cast<uint64_t>(parts) * kWaves * kRunBlocks;
+    cap = (cap + kRunBlocks - 1) / kRunBlocks * kRunBlocks;
+    if (cap > 0xFFFFFFFFull - kRunBlocks) return VK_EINVAL;
+    const size_t per_sample = static_cast<size_t>(PARTS) * cap * 128u;
+    uint32_t batch = static_cast<uint32_t>(ctx->spill_budget / per_sample);
+    if (batch == 0) batch = 1;
+    if (batch > nsamples) batch = nsamples;
+    const size_t cursor_bytes = (static_cast<size_t>(batch) * PARTS * sizeof(uint32_t) + 255) / 256 * 256;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap, cursor_bytes + batch * per_sample);
+    if (rc) return rc;
+    BucketParams bp;
+    bp.cursors = ctx->d_spill;
+    bp.buckets = ctx->d_spill + cursor_bytes / sizeof(uint32_t);
+    bp.cap_blocks = static_cast<uint32_t>(cap);
+    VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
+    ctx->last_block = kCountThreads;
+    ctx->last_lds = kWaves * kPiece + 2 * 66 * 16 + kWaves * kQueueEntries * 2 + 3 * kWaves * 16 * 4;
+    for (uint32_t s0 = 0; s0 < nsamples; s0 += batch) {
+        const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
+        VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * PARTS * sizeof(uint32_t), ctx->stream));
+        ctx->last_grid = n * parts;
+        hipLaunchKernelGGL((vk_bucket_kernel<K>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                           d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
+                           ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp);
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * PARTS), dim3(kCountThreads), 0, ctx->stream, bp,
+                           d_hist + static_cast<size_t>(s0) * NCODE);
+        VK_HIP(ctx, hipGetLastError());
+    }
     return VK_OK;
 }
 
@@ -783,7 +1017,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -844,17 +1078,13 @@ int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, c
     uint64_t* d_lens = ctx->d_desc + nsamples;
     rc = upload_desc(ctx, offsets, lengths, nsamples);
     if (rc) return rc;
-    const size_t ncode = static_cast<size_t>(1) << (2 * k);
-    const int atomic_flush = parts > 1 ? 1 : 0;
-    if (atomic_flush)
-        VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * ncode * sizeof(uint32_t), ctx->stream));
     const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
     switch (k) {
-        case 5: rc = launch_count<5, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
-        case 6: rc = launch_count<6, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
-        case 7: rc = launch_count<7, 0>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
-        case 8: rc = launch_count<8, 2>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
-        default: rc = launch_count<9, 4>(ctx, fq, d_offs, d_lens, nsamples, parts, d_hist, atomic_flush); break;
+        case 5: rc = launch_count<5>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
+        case 6: rc = launch_count<6>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
+        case 7: rc = launch_count<7>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
+        case 8: rc = launch_spill<8>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
+        default: rc = launch_spill<9>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
     }
     if (rc) return rc;
     hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, d_offs, d_lens,

@@ -10,7 +10,7 @@
 //   vk_synth_kernel       synthetic FASTQ generator of BASELINE.md section 4
 //
 // Design notes live in DESIGN.md; the short version for K1:
-//   * one 1024-thread workgroup per (sample, byte-range part[, histogram part]);
+//   * one 1024-thread workgroup per (sample, byte-range part);
 //     its 16 wavefronts run WITHOUT workgroup barriers in steady state: every
 //     wave streams its own contiguous byte range in 4 KiB pieces (4 coalesced
 //     16-B loads per lane, prefetched one piece ahead), transposes the piece
@@ -21,8 +21,9 @@
 //     locally from the '@' / '+' framing, so byte ranges are independent;
 //   * k-mer windows are counted forward-strand only into an LDS histogram
 //     (ds_add_u32); the strand merge happens once per sample in K2;
-//   * 4^k u32 > LDS for k = 8, 9: the code space is split over 2^LOG_PARTS
-//     sibling workgroups that read the same bytes (kept on one XCD for L2 reuse).
+//   * 4^k u32 > LDS for k = 8, 9: windows are bucketed through wave-private LDS queues into
+//     per-part streams in HBM and replayed into 16384-bin LDS histograms (vk_bucket_kernel,
+//     vk_bucket_count_kernel).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -36,3 +36,29 @@ def edge_cases():
                                for i in range(4000))
     cases["exact_64_multiple"] = b"".join(rec("%06d" % i, rand_seq(rng, 24)) for i in range(1024))  # 64 B records
     return cases
+
+
+def random_fastq(rng, nrec=None):
+    """A structurally valid 4-line FASTQ with adversarial content: zero-length and very long reads,
+    IUPAC / lower-case / punctuation in sequences, '@' and '+' leading quality lines, long or empty
+    header tails, optional CRLF, optional missing final newline."""
+    nrec = int(rng.integers(1, 60)) if nrec is None else nrec
+    alph = [list("ACGT"), list("ACGTN"), list("ACGTacgtNnRYKM.-*"), list("AC")]
+    out = []
+    crlf = rng.random() < 0.15
+    eol = b"\r\n" if crlf else b"\n"
+    for i in range(nrec):
+        a = alph[int(rng.integers(0, len(alph)))]
+        mode = rng.random()
+        n = 0 if mode < 0.05 else int(rng.integers(1, 12)) if mode < 0.2 else int(rng.integers(12, 400)) \
+            if mode < 0.95 else int(rng.integers(400, 6000))
+        seq = "".join(rng.choice(a, size=n)) if n else ""
+        q0 = rng.choice(list("@+I5#"))
+        qual = (q0 + "".join(rng.choice(list("!#5ACGT@+IJ~"), size=max(n - 1, 0))))[:n]
+        hdr = "@" + "".join(rng.choice(list("abcXYZ012:/ _ACGT@+"), size=int(rng.integers(0, 90))))
+        plus = "+" + (hdr[1:] if rng.random() < 0.2 else "")
+        out.append(hdr.encode() + eol + seq.encode() + eol + plus.encode() + eol + qual.encode() + eol)
+    data = b"".join(out)
+    if rng.random() < 0.3 and not crlf and n > 0:
+        data = data[:-1]  # no final newline (only meaningful when the last quality line is not empty)
+    return data

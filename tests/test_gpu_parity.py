@@ -186,3 +186,22 @@ def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
         assert int(got[0].sum(dtype=np.uint64)) == nwin
         assert np.array_equal(got[0], want), parts
         assert np.array_equal(got[1], want2), parts
+
+
+@pytest.mark.parametrize("k", KS)
+def test_count_fuzz_batches(engines, k):
+    """Hundreds of random adversarial (well-formed) FASTQ samples per launch, random workgroup
+    splits: every histogram equals the oracle's."""
+    from fastq_cases import random_fastq
+    rng = np.random.default_rng(100 + k)
+    eng = engines(k)
+    for rnd in range(3):
+        samples = [random_fastq(rng) for _ in range(150)]
+        want = np.stack([oracle.count_fastq(s, k)[0] for s in samples])
+        dev, offs, lens = eng.upload(samples)
+        for parts in (1, int(rng.integers(2, 6))):
+            hist, status = eng.count(dev, offs, lens, parts=parts)
+            assert not status.cpu().numpy().any(), (rnd, parts)
+            got = hist.cpu().numpy().view(np.uint32)
+            bad = np.nonzero((got != want).any(axis=1))[0]
+            assert bad.size == 0, (rnd, parts, bad[:5])

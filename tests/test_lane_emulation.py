@@ -63,3 +63,18 @@ def test_emulated_wave_flags_bad_framing(emul):
     assert emul(good, 7, 1)[1] == 0
     assert emul(good[1:], 7, 1)[1] & 1
     assert emul(good[:-200], 7, 2)[1] & 2
+
+
+def test_emulated_wave_fuzz(emul):
+    """Random adversarial (but well-formed) FASTQ: emulated wave algorithm == oracle."""
+    from fastq_cases import random_fastq
+    rng = np.random.default_rng(2024)
+    for trial in range(120):
+        fq = random_fastq(rng)
+        k = int(rng.integers(5, 10))
+        want, nwin, st = oracle.count_fastq(fq, k)
+        assert st == 0
+        parts = int(rng.integers(1, 4))
+        got, status = emul(fq, k, parts)
+        assert status == 0, trial
+        assert np.array_equal(got, want), (trial, k, parts, len(fq))

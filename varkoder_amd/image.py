@@ -8,7 +8,6 @@ fallback: without the HIP library and a GPU these functions raise.
 """
 import gzip
 import hashlib
-import io
 import struct
 import sys
 from collections import OrderedDict

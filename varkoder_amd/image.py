@@ -15,7 +15,6 @@ from pathlib import Path
 
 import numpy as np
 
-from . import _capi
 from .config import BP_KMER_SEP, LABELS_SEP, QUAL_THRESH
 from .mapping import lut_from_dataframe
 
@@ -71,42 +70,78 @@ def read_counts(path):
     return k, np.frombuffer(raw, dtype="<u4", offset=12).astype(np.uint32)
 
 
+def _stem(path):
+    """File name minus ALL suffixes (the reference's naming rule, image.py:753, :840)."""
+    p = Path(path)
+    return str(p.name.removesuffix("".join(p.suffixes)))
+
+
+def counts_name(infile, k):
+    """`<stem>+k<k>.fq.h5` (image.py:752-759)."""
+    return f"{_stem(infile)}{BP_KMER_SEP}k{k}.fq.h5"
+
+
+def png_name(counts_file, mapping_code):
+    """`<sample>@<bp>K+<mapping>+k<k>.png` from a counts file name (image.py:840-849)."""
+    base, in_k = _stem(counts_file).split(BP_KMER_SEP)
+    return BP_KMER_SEP.join((base, mapping_code, in_k)) + ".png"
+
+
+def shard_folder(outfolder, outfile, subfolder_levels):
+    """md5-hex sharding directories, popped from the END of the digest (image.py:850-854)."""
+    outfolder = Path(outfolder)
+    if subfolder_levels:
+        digest = list(hashlib.md5(outfile.encode("UTF-8")).hexdigest())
+        for _ in range(subfolder_levels):
+            outfolder = outfolder / digest.pop()
+    return outfolder
+
+
+def write_png(arr, path, labels, base_sd, base_sd_thresh, mapping_code):
+    """8-bit "L" PNG, optimize=True, with the four varkoder* text chunks in the reference's order
+    (image.py:920-930)."""
+    from PIL import Image
+    from PIL.PngImagePlugin import PngInfo
+    chunks = PngInfo()
+    for key, value in (("varkoderKeywords", LABELS_SEP.join(labels)),
+                       ("varkoderBaseFreqSd", str(base_sd)),
+                       ("varkoderLowQualityFlag", str(base_sd > base_sd_thresh)),
+                       ("varkoderMapping", mapping_code)):
+        chunks.add_text(key, value)
+    Image.fromarray(arr).save(path, optimize=True, pnginfo=chunks)
+
+
+def _seconds_since(t0):
+    import pandas as pd
+    return (pd.Timestamp.now() - t0).total_seconds()
+
+
 def count_kmers(infile, outfolder, threads=1, k=7, overwrite=False, verbose=False):
     """Count k-mers in a FASTQ file (drop-in for commands/image.py:727-806).
 
-    Writes forward-strand counts to `<name minus suffixes>+k<k>.fq.h5` in outfolder
-    (same file name rule, :752-759; the content is this package's own container, it
-    is only ever read back by make_image).  Returns OrderedDict
-    {"<k>mer_counting_time": seconds}, or an empty one when the file exists and
-    overwrite is False (:761-763).  Raises on failure like the reference's
-    check=True subprocess does; `threads` is accepted for signature parity.
+    Writes forward-strand counts to `<name minus suffixes>+k<k>.fq.h5` in outfolder (same file
+    name rule; the content is this package's own container, only ever read back by make_image).
+    Returns OrderedDict {"<k>mer_counting_time": seconds}, or an empty one when the file exists
+    and overwrite is False (:761-763).  Raises on failure like the reference's check=True
+    subprocess does; `threads` is accepted for signature parity.
     """
     import pandas as pd
-    start_time = pd.Timestamp.now()
-
+    t0 = pd.Timestamp.now()
     Path(outfolder).mkdir(exist_ok=True)
-    outfile = (str(Path(infile).name.removesuffix("".join(Path(infile).suffixes)))
-               + BP_KMER_SEP + "k" + str(k) + ".fq.h5")
-    outpath = Path(outfolder) / outfile
-
-    if not overwrite and outpath.is_file():
+    outpath = Path(outfolder) / counts_name(infile, k)
+    if outpath.is_file() and not overwrite:
         eprint("File exists. Skipping kmer counting for file:", str(infile))
         return OrderedDict()
 
     data = read_fastq_bytes(infile)
-    eng = _engine(k, "count")
-    hist, status = eng.count_host(data)
+    hist, status = _engine(k, "count").count_host(data)
     if status:
         raise RuntimeError(f"k-mer counting failed for {infile}: inconsistent FASTQ framing "
                            f"(status bits {status})")
     if verbose:
         eprint(f"vk_count_host k={k} bytes={len(data)} windows={int(hist.sum(dtype=np.uint64))}")
     write_counts(outpath, k, hist)
-
-    done_time = pd.Timestamp.now()
-    stats = OrderedDict()
-    stats[str(k) + "mer_counting_time"] = (done_time - start_time).total_seconds()
-    return stats
+    return OrderedDict([(f"{k}mer_counting_time", _seconds_since(t0))])
 
 
 def image_array(hist, kmer_mapping):
@@ -116,61 +151,33 @@ def image_array(hist, kmer_mapping):
     if hist.size != 4 ** k:
         raise IndexError("k-mer counts do not match the k-mer mapping size")
     key = hashlib.sha1(np.ascontiguousarray(lut).tobytes()).hexdigest()
-    eng = _engine(k, key, lut=lut, npix=npix)
-    return eng.image_host(hist)
+    return _engine(k, key, lut=lut, npix=npix).image_host(hist)
 
 
 def make_image(infile, outfolder, kmer_mapping, threads=1, overwrite=False, verbose=False, labels=[],
                base_sd=0, base_sd_thresh=QUAL_THRESH, subfolder_levels=0, mapping_code="varKode"):
     """Create an image from k-mer counts (drop-in for commands/image.py:808-936).
 
-    Output name `<sample>@<bp>K+<mapping>+k<k>.png` (:840-849), optional md5-hex
-    sharding folders (:850-854), skip-if-exists returning an empty OrderedDict
-    (:857-859), 8-bit "L" PNG with the four varkoder* text chunks in the reference's
-    order (:923-927), and {"k<k>_img_time": seconds} (:932-936).  A counts file with
-    no k-mers raises pandas' EmptyDataError exactly as the reference's read_csv of an
-    empty dsk2ascii dump does (:897-899).
+    Output name `<sample>@<bp>K+<mapping>+k<k>.png`, optional md5-hex sharding folders,
+    skip-if-exists returning an empty OrderedDict (:857-859), PNG + metadata as the reference
+    writes them, and {"k<k>_img_time": seconds} (:932-936).  A counts file with no k-mers raises
+    pandas' EmptyDataError exactly as the reference's read_csv of an empty dsk2ascii dump does
+    (:897-899).
     """
     import pandas as pd
-    from PIL import Image
-    from PIL.PngImagePlugin import PngInfo
-
-    in_basename = str(Path(infile).name.removesuffix("".join(Path(infile).suffixes)))
-    in_base1, in_k = in_basename.split(BP_KMER_SEP)
-
-    outfile = in_base1 + BP_KMER_SEP + mapping_code + BP_KMER_SEP + in_k + ".png"
-    outfolder = Path(outfolder)
-    if subfolder_levels:
-        hsh = list(hashlib.md5(outfile.encode("UTF-8")).hexdigest())
-        for i in range(subfolder_levels):
-            outfolder = outfolder / hsh.pop()
-    Path(outfolder).mkdir(exist_ok=True, parents=True)
-
-    if not overwrite and (outfolder / outfile).is_file():
+    outfile = png_name(infile, mapping_code)
+    folder = shard_folder(outfolder, outfile, subfolder_levels)
+    folder.mkdir(exist_ok=True, parents=True)
+    if (folder / outfile).is_file() and not overwrite:
         eprint("File exists. Skipping image for file:", str(infile))
         return OrderedDict()
 
-    start_time = pd.Timestamp.now()
-    kmer_size = len(kmer_mapping.index[0])
-
+    t0 = pd.Timestamp.now()
+    kmer_size = len(kmer_mapping.index[0])  # image.py:862
     k_file, hist = read_counts(infile)
     if k_file != kmer_size:
         raise IndexError(f"{infile}: counted with k={k_file} but the mapping has k={kmer_size}")
     if not hist.any():
         raise pd.errors.EmptyDataError("No columns to parse from file")
-
-    kmer_array = image_array(hist, kmer_mapping)
-    img = Image.fromarray(kmer_array)  # uint8 2-D -> mode "L"
-
-    metadata = PngInfo()
-    metadata.add_text("varkoderKeywords", LABELS_SEP.join(labels))
-    metadata.add_text("varkoderBaseFreqSd", str(base_sd))
-    metadata.add_text("varkoderLowQualityFlag", str(base_sd > base_sd_thresh))
-    metadata.add_text("varkoderMapping", mapping_code)
-
-    img.save(Path(outfolder) / outfile, optimize=True, pnginfo=metadata)
-
-    done_time = pd.Timestamp.now()
-    stats = OrderedDict()
-    stats["k" + str(kmer_size) + "_img_time"] = (done_time - start_time).total_seconds()
-    return stats
+    write_png(image_array(hist, kmer_mapping), folder / outfile, labels, base_sd, base_sd_thresh, mapping_code)
+    return OrderedDict([(f"k{kmer_size}_img_time", _seconds_since(t0))])

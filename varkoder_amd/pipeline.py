@@ -6,35 +6,20 @@ Steps B/C of the reference (fastp, reformat.sh) are external tools that are out 
 path's scope; this module enters where the reference enters step D: with
 files named `<sample>@<bp>K.fq[.gz]` as split_fastq leaves them (image.py:699-709).
 """
-import hashlib
 import time
 from collections import OrderedDict
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
-import numpy as np
 
-from .config import BP_KMER_SEP, LABELS_SEP, QUAL_THRESH
-from .image import eprint, read_fastq_bytes
+from .config import QUAL_THRESH
+from .image import counts_name, eprint, png_name, read_fastq_bytes, shard_folder, write_png
 from .shard import shard_indices
 
 
 def image_name(fastq_path, k, mapping_code):
-    """`<sample>@<bp>K+<mapping>+k<k>.png` (image.py:752-759 then :840-849)."""
-    p = Path(fastq_path)
-    stem = str(p.name.removesuffix("".join(p.suffixes)))
-    return stem + BP_KMER_SEP + mapping_code + BP_KMER_SEP + "k" + str(k) + ".png"
-
-
-def save_png(arr, path, labels, base_sd, base_sd_thresh, mapping_code):
-    from PIL import Image
-    from PIL.PngImagePlugin import PngInfo
-    meta = PngInfo()  # image.py:923-927, same keys in the same order
-    meta.add_text("varkoderKeywords", LABELS_SEP.join(labels))
-    meta.add_text("varkoderBaseFreqSd", str(base_sd))
-    meta.add_text("varkoderLowQualityFlag", str(base_sd > base_sd_thresh))
-    meta.add_text("varkoderMapping", mapping_code)
-    Image.fromarray(arr).save(path, optimize=True, pnginfo=meta)
+    """`<sample>@<bp>K+<mapping>+k<k>.png` straight from a split FASTQ's name."""
+    return png_name(counts_name(fastq_path, k), mapping_code)
 
 
 def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_sd=None, overwrite=False,
@@ -57,12 +42,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
 
     def target(f):
         name = image_name(f, k, mapping_code)
-        d = outdir
-        if subfolder_levels:
-            hsh = list(hashlib.md5(name.encode("UTF-8")).hexdigest())
-            for _ in range(subfolder_levels):
-                d = d / hsh.pop()
-        return d, name
+        return shard_folder(outdir, name, subfolder_levels), name
 
     todo = []
     for f in mine:
@@ -102,7 +82,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
             sample = key.split("@")[0]
             sd = base_sd.get(sample, 0)
             pending.append((key, time.perf_counter(),
-                            pool.submit(save_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
+                            pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
                                         QUAL_THRESH, mapping_code)))
         if verbose:
             eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")

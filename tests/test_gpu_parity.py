@@ -205,3 +205,22 @@ def test_count_fuzz_batches(engines, k):
             got = hist.cpu().numpy().view(np.uint32)
             bad = np.nonzero((got != want).any(axis=1))[0]
             assert bad.size == 0, (rnd, parts, bad[:5])
+
+
+def test_giant_sample_ranges_sum_to_the_whole(engines):
+    """SURVEY 8e optional row: one sample cut at record boundaries into per-rank byte ranges;
+    the per-range GPU histograms sum to the whole-sample histogram (what the RCCL all-reduce of
+    engine.count_giant_sample computes across ranks)."""
+    from varkoder_amd.engine import count_giant_sample
+    from varkoder_amd.shard import split_at_records
+    eng = engines(7)
+    fq = synth.sample_fastq(500, 40000, 150, dist=1).tobytes()
+    want = oracle.count_fastq(fq, 7)[0].astype(np.int64)
+    h, st = count_giant_sample(eng, fq)                      # world = 1: no collective
+    assert st == 0 and np.array_equal(h.cpu().numpy(), want)
+    total = np.zeros_like(want)
+    for s, e in split_at_records(fq, 4):
+        hist, status = eng.count_host(fq[s:e])
+        assert status == 0
+        total += hist
+    assert np.array_equal(total, want)

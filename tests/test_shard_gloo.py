@@ -78,3 +78,59 @@ def test_single_process_helpers_are_identity():
     assert shard.max_over_ranks(3.5) == 3.5
     assert shard.gather_stats({"a": {"x": 1}}) == {"a": {"x": 1}}
     assert shard.world_info()[1] >= 1
+
+
+def _giant_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from varkoder_amd import shard, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fq = synth.sample_fastq(77, 3000, 150, dist=1).tobytes()
+    start, end = shard.split_at_records(fq, world)[rank]
+    part = fq[start:end]
+    h, nwin, st = oracle.count_fastq(part, 7)          # stands in for the GPU count of this range
+    t = torch.from_numpy(h.astype(np.int64))
+    shard.allreduce_sum_(t)
+    if rank == 0:
+        out.put((st, t.numpy().copy(), (start, end)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_giant_sample_split_and_allreduce_is_exact():
+    """One sample over two ranks: record-aligned split + SUM all-reduce of the histograms equals
+    the histogram of the whole sample (integer, order-independent)."""
+    from oracle import oracle
+    from varkoder_amd import shard, synth
+    from fastq_cases import rec
+    fq = synth.sample_fastq(77, 3000, 150, dist=1).tobytes()
+    want = oracle.count_fastq(fq, 7)[0].astype(np.int64)
+    for world in (2, 3, 7):
+        ranges = shard.split_at_records(fq, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(fq)
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        total = np.zeros_like(want)
+        for s, e in ranges:
+            assert e == s or fq[s:s + 1] == b"@"
+            h, _, st = oracle.count_fastq(fq[s:e], 7)
+            assert st == 0
+            total += h
+        assert np.array_equal(total, want)
+    # quality lines that start with '@' must not be taken for headers
+    tricky = b"".join(rec(f"r{i}", "ACGTACGTAC" * 3, qual="@" + "+" * 29) for i in range(400))
+    for s, e in shard.split_at_records(tricky, 5):
+        assert oracle.count_fastq(tricky[s:e], 5)[2] == 0
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_giant_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    st, total, _ = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert st == 0 and np.array_equal(total, want)

@@ -176,3 +176,18 @@ class ImageEngine:
                                   img.ctypes.data_as(C.POINTER(C.c_uint8)))
         _capi.check(self.ctx, st, "vk_image_host")
         return img.reshape(self.side, self.side)
+
+
+def count_giant_sample(engine, data, rank=0, world=1):
+    """ONE sample spread over the ranks of a torch.distributed job (optional row): every
+    rank counts a record-aligned byte range of the FASTQ text on its own GPU, then the 4^k u32
+    histograms are summed with one all-reduce (RCCL when the group is nccl).  Returns the full
+    histogram tensor (identical on every rank) and this rank's status word."""
+    from .shard import allreduce_sum_, split_at_records
+    start, end = split_at_records(data, world)[rank]
+    part = data[start:end]
+    dev, offs, lens = engine.upload([part])
+    hist, status = engine.count(dev, offs, lens)
+    h = hist.view(-1).to(_torch().int64)      # sum in 64 bit, counts of a giant sample may pass 2^31
+    allreduce_sum_(h)
+    return h, int(status.cpu()[0])

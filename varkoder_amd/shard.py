@@ -56,3 +56,51 @@ def gather_stats(local_stats, dst=0):
         for k in sorted(part):
             merged.setdefault(k, OrderedDict()).update(part[k])
     return OrderedDict(sorted(merged.items()))
+
+
+def split_at_records(data, nparts, window=1 << 16):
+    """Byte ranges [(start, end)] that cut one FASTQ text into `nparts` pieces at record starts, so
+    that every piece is a well-formed FASTQ on its own (used to spread ONE giant sample over the
+    ranks of a job; the kernels do the same recovery per wavefront, csrc/vkimg.hip sync_phase).
+
+    A line start l is a header iff byte[l] == '@' and the line two lines later starts with '+'
+    (a quality line may start with '@', but then that later line is a sequence line).  `data` is
+    anything sliceable into bytes (bytes, memoryview, numpy uint8 array).
+    """
+    n = len(data)
+    cuts = [0]
+    for p in range(1, nparts):
+        target = n * p // nparts
+        if target <= cuts[-1]:
+            cuts.append(cuts[-1])
+            continue
+        chunk = bytes(data[target:min(n, target + window)])
+        nl = []
+        pos = -1
+        while len(nl) < 6:
+            pos = chunk.find(b"\n", pos + 1)
+            if pos < 0:
+                break
+            nl.append(pos)
+        cut = None
+        for i in range(max(0, min(4, len(nl) - 2))):
+            li, lj = nl[i] + 1, nl[i + 2] + 1
+            if lj < len(chunk) and chunk[li:li + 1] == b"@" and chunk[lj:lj + 1] == b"+":
+                cut = target + li
+                break
+        if cut is None:          # no record start in the window (end of file, or giant lines)
+            cut = n
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(n)
+    return [(cuts[i], cuts[i + 1]) for i in range(nparts)]
+
+
+def allreduce_sum_(hist):
+    """In-place SUM all-reduce of a histogram tensor over the default group: the one data-path
+    collective of this package (RCCL over xGMI when the group is `nccl`; 64 KB at k=7, 1 MB at
+    k=9 -- latency-bound, any algorithm fits one link).  Integer addition is associative, so the
+    result is exact and independent of the reduction order."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+    return hist

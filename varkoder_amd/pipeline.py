@@ -13,7 +13,7 @@ from pathlib import Path
 
 
 from .config import QUAL_THRESH
-from .image import counts_name, eprint, png_name, read_fastq_bytes, shard_folder, write_png
+from .image import counts_name, eprint, png_name, shard_folder, write_png
 from .shard import shard_indices
 
 
@@ -52,24 +52,27 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
             continue
         todo.append(f)
 
+    import os
     i = 0
     while i < len(todo):
+        # batch by on-disk size (gzip files count 4x: they are inflated on the host first)
         batch, nbytes = [], 0
         t0 = time.perf_counter()
-        for data, f in zip(pool.map(read_fastq_bytes, todo[i:i + 4 * io_threads]), todo[i:]):
-            if batch and nbytes + len(data) > batch_bytes:
+        for f in todo[i:]:
+            sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
+            if batch and nbytes + sz > batch_bytes:
                 break
-            batch.append((f, data))
-            nbytes += len(data)
+            batch.append(f)
+            nbytes += sz
         i += len(batch)
-        dev, offs, lens = eng.upload([d for _, d in batch])
+        dev, offs, lens = eng.upload_files(batch, pool)
         t1 = time.perf_counter()
         img, hist, status = eng.fastq_to_images(dev, offs, lens)
         st = status.cpu().numpy()
         imgs = img.cpu().numpy()
         nz = (hist != 0).any(dim=1).cpu().numpy()
         t2 = time.perf_counter()
-        for j, (f, _) in enumerate(batch):
+        for j, f in enumerate(batch):
             key = str(f.name.removesuffix("".join(f.suffixes)))
             s = stats.setdefault(key, OrderedDict())
             if st[j] or not nz[j]:

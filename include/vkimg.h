@@ -22,6 +22,11 @@
  *     rounded end of the last sample.
  *   - All work is enqueued on the context's stream; *_host calls synchronise
  *     before returning, *_device calls do not.
+ *   - A context owns device workspaces that grow on demand and is NOT re-entrant: use it
+ *     from one thread at a time (one context per worker thread / process is the intended
+ *     model: the reference runs one sample per pool worker, image.py:1281-1284).
+ *   - k = 8, 9 count through a bucketed two-pass path whose workspace is about twice the
+ *     FASTQ bytes of the samples in flight; large batches are processed in sub-batches.
  */
 #ifndef VKIMG_H
 #define VKIMG_H

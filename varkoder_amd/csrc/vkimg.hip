@@ -192,11 +192,92 @@ __device__ __forceinline__ WaveRange wave_range(uint64_t len, uint32_t parts, ui
 // for every countable K-mer window (raw field: first base least significant, vk_lane.h);
 // after_group() runs after every 16 positions.  `st` is the wave's private 4 KiB LDS slot,
 // below/above the shared mask tables.  Returns the line phase at w0 and at w1.
-template <int K, typename Emit, typename Hook>
+// Window loop of the LDS-histogram kernels (K <= 7): same arithmetic as vkl::windows<K>, with the
+// predicated histogram update written out.  hipcc lowers `if (carry) atomicAdd(...)` to
+//   v_add_co -> s_and_saveexec -> s_cbranch_execz -> address VALU -> ds_add -> s_or exec
+// per position: one long VALU -> SALU -> branch -> VALU -> LDS dependency chain (measured ~76
+// cycles per position, 59 % of the kernel).  Here eight positions form one block:
+//   8 x v_add_co_u32 w, s[pair_j], w, w      carry-outs (= lane predicates) parked in SGPR pairs
+//   8 x { s_mov_b64 exec, s[pair_j] ; ds_add_u32 addr_j, one }
+//   s_mov_b64 exec, -1
+// so the VALU -> SALU hand-over is paid once per block and the addresses are ordinary VALU work
+// the scheduler hoists.  Requires EXEC = all ones on entry (wave_stream runs with the whole wave
+// active) and leaves it so.  lds_base = byte offset of the histogram in LDS.
+template <int K>
+__device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], const uint32_t ok[4],
+                                            uint32_t lds_base) {
+    static_assert(2 * K + 2 <= 16, "paired extraction needs the field << 2 to fit 16 bits");
+    const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+    constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+    const uint32_t one = 1u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // even bits: OK of positions 0..15 of this dword; odd bits: the same rotated by 8
+        // positions -> shifting out the top bit twice yields positions (i - 8, i), i = 15..8
+        uint32_t w = ok[g] | (vkl::alignbit(ok[g], ok[g], 16u) << 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t a[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 15 - 4 * half - j;
+                const int plo = 16 * g + i - 8;
+                const int o = 30 + 2 * (plo - K + 1);
+                const int word = o >> 5, sh = o & 31;
+                uint32_t x;
+                if (sh == 0) x = v[word];
+                else if (word == 4) x = v[4] >> sh;
+                else x = vkl::alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+                a[2 * j] = (x & kMask4) + lds_base;              // position i - 8 (first carry)
+                a[2 * j + 1] = ((x >> 16) & kMask4) + lds_base;  // position i
+            }
+            unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+            asm volatile(
+                "v_add_co_u32_e64 %0, %1, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %2, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %3, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %4, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %5, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %6, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %7, %0, %0\n\t"
+                "v_add_co_u32_e64 %0, %8, %0, %0\n\t"
+                "s_mov_b64 exec, %1\n\tds_add_u32 %9, %17\n\t"
+                "s_mov_b64 exec, %2\n\tds_add_u32 %10, %17\n\t"
+                "s_mov_b64 exec, %3\n\tds_add_u32 %11, %17\n\t"
+                "s_mov_b64 exec, %4\n\tds_add_u32 %12, %17\n\t"
+                "s_mov_b64 exec, %5\n\tds_add_u32 %13, %17\n\t"
+                "s_mov_b64 exec, %6\n\tds_add_u32 %14, %17\n\t"
+                "s_mov_b64 exec, %7\n\tds_add_u32 %15, %17\n\t"
+                "s_mov_b64 exec, %8\n\tds_add_u32 %16, %17\n\t"
+                "s_mov_b64 exec, -1"
+                : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one)
+                : "memory");
+        }
+    }
+}
+
+#ifdef VK_STAMPS
+// Diagnostic build only (tools/stamps.sh): per-segment cycle sums of the piece loop, written to a
+// debug buffer that nothing else reads.  Never quote this build's run time.
+__device__ unsigned long long g_vk_stamps[8];
+#define VK_STAMP(t)                                                         \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#else
+#define VK_STAMP(t) \
+    do {            \
+    } while (0)
+#endif
+
+template <int K, bool LDS_HIST, typename Emit, typename Hook>
 __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
                                             uint64_t w1, uint4* st, const uint4* below, const uint4* above,
                                             int lane, Emit emit, Hook after_group, uint32_t& ph_start,
-                                            uint32_t& ph_end) {
+                                            uint32_t& ph_end, uint32_t lds_hist_base = 0) {
     const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(st), lane) : 0u;
     ph_start = ph0;
 
@@ -239,7 +320,11 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
         return m;
     };
+#ifdef VK_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc[4] = {0, 0, 0, 0};
+#endif
     for (uint64_t it = 0; it < npieces; ++it) {
+        VK_STAMP(t0);
         // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
         wave_lds_fence();
         st[lane] = r0;
@@ -252,9 +337,11 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
         const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        VK_STAMP(t1);
         vkl::LaneBits lb;
         const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
 
+        VK_STAMP(t2);
         // newline prefix over the wave -> line phase at the start of each lane's block
         const uint32_t incl = wave_inclusive_sum(c);
         const uint32_t total = lane_bcast(incl, 63);
@@ -274,9 +361,21 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
 
         vkl::ok_mask<K>(badh, bad, ok);
         if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
-        vkl::windows<K>(ch, lb.C, ok, emit, after_group);
+        VK_STAMP(t3);
+        if constexpr (LDS_HIST) windows_lds<K>(ch, lb.C, ok, lds_hist_base);
+        else vkl::windows<K>(ch, lb.C, ok, emit, after_group);
         pph += total;
+#ifdef VK_STAMPS
+        VK_STAMP(t4);
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; acc[3] += t4 - t3;
+#endif
     }
+#ifdef VK_STAMPS
+    if (lane == 0 && blockIdx.x == 300) {
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_vk_stamps[i], acc[i]);
+        atomicAdd(&g_vk_stamps[4], npieces);
+    }
+#endif
     ph_end = pph & 3u;
 }
 
@@ -323,7 +422,11 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
         auto emit = [&](uint32_t a4) {  // a4 = raw field << 2 = byte offset into the histogram
             atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + a4), 1u);
         };
-        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, [] {}, ph_start, ph_end);
+        const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) uint32_t*)hist));
+        wave_stream<K, true>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, [] {}, ph_start, ph_end,
+                             hist_base);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 
@@ -467,7 +570,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
                 drain(static_cast<uint32_t>(q), n, n / kBlockEntries);
             }
         };
-        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, after_group, ph_start,
+        wave_stream<K, false>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, after_group, ph_start,
                        ph_end);
         // final drain: pad the last partial block of every queue, then the rest of every run
         wave_lds_fence();
@@ -1210,6 +1313,12 @@ int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t np
     VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VK_OK;
 }
+
+#ifdef VK_STAMPS
+int vk_debug_read_stamps(unsigned long long* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vk_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes) {
     if (!ctx) return VK_EINVAL;

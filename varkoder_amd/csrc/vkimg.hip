@@ -445,21 +445,27 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
 
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
 // 4^K u32 counters do not fit LDS.  Pass A streams the FASTQ exactly like vk_count_kernel but
-// appends every window's low 14 bits to one of PARTS = 4^(K-7) wave-private LDS queues chosen by
-// the window's top bits, and drains full queues as 128-byte blocks into per-(sample, part)
-// bucket streams in HBM (block runs reserved with one global atomic per 32 blocks).  Pass B
-// gives every (sample, part) one workgroup that replays its stream into a 16384-bin LDS
+// appends every window's low 2K-4 bits to one of 16 wave-private LDS queues chosen by the
+// window's top 4 bits, and drains full 64-entry blocks (128 B) into per-(sample, queue) bucket
+// streams in HBM.  The drain handles all 16 queues at once, four lanes per queue; block runs are
+// reserved 32 at a time with one global atomic, unused run tails are padded with 0xFFFF.  Pass B
+// gives every (sample, queue) one workgroup that replays its stream into a 4^K/16-bin LDS
 // histogram.  Entries that cannot be queued or whose bucket is full are counted with global
 // atomics on the spot: slower, still exact.
+constexpr uint32_t kQueues = 16;         // queues per wave = bucket streams per sample
+constexpr uint32_t kQueueCap = 128;      // u16 entries per queue (two blocks)
 constexpr uint32_t kBlockEntries = 64;   // u16 entries per 128-byte bucket block
 constexpr uint32_t kRunBlocks = 32;      // blocks reserved per global atomic
-constexpr uint32_t kQueueEntries = 2048; // u16 entries of queue space per wave (all parts)
 
 struct BucketParams {
-    uint32_t* cursors;   // [nsamples][PARTS] next free block of each bucket stream
-    uint32_t* buckets;   // [nsamples][PARTS][cap_blocks * 32] dwords
+    uint32_t* cursors;   // [nsamples][16] next free block of each bucket stream
+    uint32_t* buckets;   // [nsamples][16][cap_blocks * 32] dwords
     uint32_t cap_blocks; // multiple of kRunBlocks
 };
+
+__device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
+}
 
 template <int K>
 __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
@@ -467,18 +473,17 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t PARTS = NCODE >> 14;
-    constexpr uint32_t QCAP = kQueueEntries / PARTS;  // entries per (wave, part) queue
-    constexpr uint32_t FLUSH_AT = QCAP / 2;
-    static_assert(QCAP >= 2 * kBlockEntries, "queue must hold two blocks");
+    constexpr uint32_t LB = 2 * K - 4;               // local bits of an entry
+    constexpr uint32_t LMASK = (1u << LB) - 1u;
+    static_assert(LB <= 15, "entries are u16 with 0xFFFF as padding");
 
     __shared__ uint4 stage[kWaves][kPiece / 16];
     __shared__ uint4 below[66];
     __shared__ uint4 above[66];
-    __shared__ uint32_t qbuf[kWaves][kQueueEntries / 2];  // u16 entries, two per dword
-    __shared__ uint32_t qcnt[kWaves][16];
-    __shared__ uint32_t runbase[kWaves][16];
-    __shared__ uint32_t runleft[kWaves][16];
+    __shared__ uint4 qbuf[kWaves][kQueues * kQueueCap / 8];  // u16 entries, eight per uint4
+    __shared__ uint32_t qcnt[kWaves][kQueues];
+    __shared__ uint32_t runbase[kWaves][kQueues];
+    __shared__ uint32_t runleft[kWaves][kQueues];
 
     const uint32_t unit = blockIdx.x;
     const uint32_t s = unit / parts;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     const int wave = tid >> 6;
 
     fill_mask_tables(below, above, tid);
-    if (lane < 16) {
+    if (lane < static_cast<int>(kQueues)) {
         qcnt[wave][lane] = 0u;
         runbase[wave][lane] = 0u;
         runleft[wave][lane] = 0u;
@@ -501,108 +506,120 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     uint32_t* hist_s = hist_out + static_cast<uint64_t>(s) * NCODE;
     uint16_t* q16 = reinterpret_cast<uint16_t*>(&qbuf[wave][0]);
 
-    // write `nb` blocks of 0xFFFF padding at block index `base` of bucket (s, q)
-    auto pad_blocks = [&](uint32_t q, uint32_t base, uint32_t nb) {
-        uint32_t* dst = bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) * bp.cap_blocks * 32u +
-                        static_cast<uint64_t>(base) * 32u;
-        for (uint32_t dw = lane; dw < nb * 32u; dw += 64) dst[dw] = 0xFFFFFFFFu;
-    };
-    // drain the first `nb` blocks of queue q (wave-uniform arguments)
-    auto drain = [&](uint32_t q, uint32_t n, uint32_t nb) {
+    // Four lanes per queue: q = lane / 4, every lane moves 32 B of a 128-byte block.
+    const uint32_t q = static_cast<uint32_t>(lane) >> 2, sub = static_cast<uint32_t>(lane) & 3u;
+    const uint32_t cap_blocks = bp.cap_blocks;
+    uint32_t* const cursor = bp.cursors + (s * kQueues + q);
+    uint4* const gq = reinterpret_cast<uint4*>(bp.buckets + (static_cast<uint64_t>(s) * kQueues + q) * cap_blocks * 32u);
+
+    // Drain `nb` (0..2, per queue) blocks from the front of every queue.  All lanes call it.
+    auto drain_all = [&](uint32_t n, uint32_t nb) __attribute__((always_inline)) {
         uint32_t base = runbase[wave][q], left = runleft[wave][q];
-        bool have = true;
-        if (left < nb) {
-            if (left) pad_blocks(q, base, left);  // the rest of the old run stays padding
-            uint32_t nbase = 0;
-            if (lane == 0) nbase = atomicAdd(&bp.cursors[s * PARTS + q], kRunBlocks);
-            nbase = lane_bcast(nbase, 0);
-            have = nbase + kRunBlocks <= bp.cap_blocks;
-            base = nbase;
-            left = have ? kRunBlocks : 0u;
+        const bool need = nb > left;
+        if (need && left) {  // the rest of the old run (fewer than nb <= 2 blocks) stays padding
+            const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            gq[static_cast<uint64_t>(base) * 8u + sub * 2u] = ff;
+            gq[static_cast<uint64_t>(base) * 8u + sub * 2u + 1u] = ff;
         }
-        const uint32_t* src = &qbuf[wave][q * (QCAP / 2)];
-        if (have) {
-            uint32_t* dst = bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) * bp.cap_blocks * 32u +
-                            static_cast<uint64_t>(base) * 32u;
-            for (uint32_t dw = lane; dw < nb * 32u; dw += 64) dst[dw] = src[dw];
-            base += nb;
-            left -= nb;
-        } else {  // bucket full: count these entries directly (exact, slow)
-            for (uint32_t e = lane; e < nb * kBlockEntries; e += 64) {
-                const uint32_t loc = q16[q * QCAP + e];
-                if (loc != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << 14) | loc, K)], 1u);
+        uint32_t nbase = 0;
+        if (need && sub == 0) nbase = atomicAdd(cursor, kRunBlocks);
+        nbase = quad_bcast0(nbase);
+        if (need) {
+            base = nbase;
+            left = (nbase + kRunBlocks <= cap_blocks) ? kRunBlocks : 0u;
+        }
+        const bool store = left >= nb;  // false only when the bucket is full
+        const uint4* src = &qbuf[wave][q * (kQueueCap / 8)];
+#pragma unroll
+        for (uint32_t b = 0; b < 2; ++b) {
+            if (b < nb) {
+                const uint4 v0 = src[b * 8u + sub * 2u], v1 = src[b * 8u + sub * 2u + 1u];
+                if (store) {
+                    gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = v0;
+                    gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = v1;
+                } else {  // bucket full: count these entries directly (exact, slow)
+                    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
+                        if (lo != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << LB) | lo, K)], 1u);
+                        if (hi != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << LB) | hi, K)], 1u);
+                    }
+                }
             }
         }
-        // move the remainder (< one block) to the front
-        const uint32_t done = nb * kBlockEntries;
-        const uint32_t rem = n > done ? n - done : 0u;
+        // move the remainder (< one block) to the front: block nb -> block 0 (nb = 1 only;
+        // after two blocks nothing is left because a queue holds two)
+        uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+        if (nb == 1) {
+            k0 = src[8u + sub * 2u];
+            k1 = src[8u + sub * 2u + 1u];
+        }
         wave_lds_fence();
-        uint32_t keep = 0;
-        if (static_cast<uint32_t>(lane) < rem) keep = q16[q * QCAP + done + lane];
-        wave_lds_fence();
-        if (static_cast<uint32_t>(lane) < rem) q16[q * QCAP + lane] = static_cast<uint16_t>(keep);
-        if (lane == 0) {
-            qcnt[wave][q] = rem;
-            runbase[wave][q] = base;
-            runleft[wave][q] = left;
+        if (nb == 1) {
+            qbuf[wave][q * (kQueueCap / 8) + sub * 2u] = k0;
+            qbuf[wave][q * (kQueueCap / 8) + sub * 2u + 1u] = k1;
+        }
+        if (nb && sub == 0) {
+            qcnt[wave][q] = n - nb * kBlockEntries;
+            runbase[wave][q] = store ? base + nb : base;
+            runleft[wave][q] = store ? left - nb : 0u;
         }
         wave_lds_fence();
     };
 
     uint32_t ph_start = 0, ph_end = 0;
     if (!wr.empty) {
-        auto emit = [&](uint32_t a4) {
+        auto emit = [&](uint32_t a4) __attribute__((always_inline)) {
             const uint32_t raw = a4 >> 2;
-            const uint32_t q = raw >> 14, loc = raw & 0x3FFFu;
-            const uint32_t idx = atomicAdd(&qcnt[wave][q], 1u);  // returning LDS atomic
-            if (idx < QCAP) q16[q * QCAP + idx] = static_cast<uint16_t>(loc);
-            else atomicAdd(&hist_s[pair_reverse(raw, K)], 1u);   // queue full: exact slow path
+            const uint32_t qq = raw >> LB, loc = raw & LMASK;
+            const uint32_t idx = atomicAdd(&qcnt[wave][qq], 1u);  // returning LDS atomic
+            if (idx < kQueueCap) q16[qq * kQueueCap + idx] = static_cast<uint16_t>(loc);
+            else atomicAdd(&hist_s[pair_reverse(raw, K)], 1u);    // queue full: exact slow path
         };
-        auto after_group = [&]() {
+        auto after_group = [&]() __attribute__((always_inline)) {
             wave_lds_fence();
-            const uint32_t cnt = static_cast<uint32_t>(lane) < PARTS ? qcnt[wave][lane] : 0u;
-            unsigned long long m = __ballot(cnt >= FLUSH_AT);
-            while (m) {
-                const int q = __builtin_ctzll(m);
-                m &= m - 1;
-                uint32_t n = lane_bcast(cnt, q);
-                if (n > QCAP) n = QCAP;
-                drain(static_cast<uint32_t>(q), n, n / kBlockEntries);
-            }
+            uint32_t n = qcnt[wave][q];
+            if (n > kQueueCap) n = kQueueCap;
+            const uint32_t nb = n / kBlockEntries;
+            if (__any(nb != 0u)) drain_all(n, nb);
         };
         wave_stream<K, false>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, after_group, ph_start,
-                       ph_end);
-        // final drain: pad the last partial block of every queue, then the rest of every run
+                              ph_end);
+        // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();
-        for (uint32_t q = 0; q < PARTS; ++q) {
-            uint32_t n = qcnt[wave][q];
-            if (n > QCAP) n = QCAP;
-            const uint32_t nb = (n + kBlockEntries - 1) / kBlockEntries;
-            for (uint32_t e = n + lane; e < nb * kBlockEntries; e += 64) q16[q * QCAP + e] = 0xFFFFu;
-            wave_lds_fence();
-            if (nb) drain(q, n, nb);
-            const uint32_t left = runleft[wave][q];
-            if (left) pad_blocks(q, runbase[wave][q], left);
+        uint32_t n = qcnt[wave][q];
+        if (n > kQueueCap) n = kQueueCap;
+        const uint32_t nb = (n + kBlockEntries - 1) / kBlockEntries;
+        for (uint32_t e = n + sub; e < nb * kBlockEntries; e += 4) q16[q * kQueueCap + e] = 0xFFFFu;
+        wave_lds_fence();
+        drain_all(nb * kBlockEntries, nb);
+        const uint32_t left = runleft[wave][q], base = runbase[wave][q];
+        const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (uint32_t b = 0; b < left; ++b) {
+            gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = ff;
+            gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = ff;
         }
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 }
 
-// Pass B: one workgroup per (sample, part) replays the bucket stream into LDS and adds the
-// 16384 counters to the histogram (which already holds pass A's direct counts).
+// Pass B: one workgroup per (sample, queue) replays the bucket stream into LDS and adds the
+// 4^K/16 counters to the histogram (which already holds pass A's direct counts).
 template <int K>
 __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp,
                                                                          uint32_t* __restrict__ hist_out) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t PARTS = NCODE >> 14;
-    __shared__ uint32_t hist[16384];
-    const uint32_t s = blockIdx.x / PARTS, q = blockIdx.x % PARTS;
+    constexpr uint32_t LB = 2 * K - 4;
+    constexpr uint32_t BINS = 1u << LB;
+    __shared__ uint32_t hist[BINS];
+    const uint32_t s = blockIdx.x / kQueues, q = blockIdx.x % kQueues;
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 16384; i += kCountThreads) hist[i] = 0u;
+    for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
     __syncthreads();
-    uint32_t nblk = bp.cursors[s * PARTS + q];
+    uint32_t nblk = bp.cursors[s * kQueues + q];
     if (nblk > bp.cap_blocks) nblk = bp.cap_blocks;
-    const uint4* src = reinterpret_cast<const uint4*>(bp.buckets + (static_cast<uint64_t>(s) * PARTS + q) *
+    const uint4* src = reinterpret_cast<const uint4*>(bp.buckets + (static_cast<uint64_t>(s) * kQueues + q) *
                                                                        bp.cap_blocks * 32u);
     const uint64_t n16 = static_cast<uint64_t>(nblk) * 8u;  // 16-byte groups
     for (uint64_t i = tid; i < n16; i += kCountThreads) {
@@ -617,9 +634,9 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     }
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
-    for (uint32_t i = tid; i < 16384; i += kCountThreads) {
+    for (uint32_t i = tid; i < BINS; i += kCountThreads) {
         const uint32_t v = hist[i];
-        if (v) out[pair_reverse((q << 14) | i, K)] += v;  // this workgroup owns these codes now
+        if (v) out[pair_reverse((q << LB) | i, K)] += v;  // this workgroup owns these codes now
     }
 }
 
@@ -1030,17 +1047,16 @@ template <int K>
 int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
                  uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t PARTS = NCODE >> 14;
-    // windows <= bytes/2; a uniform sample sends ~0.45*bytes/PARTS entries to each part.  Room for
-    // bytes/PARTS entries (2.2x) plus the run each wave may leave unfinished.
-    uint64_t cap = maxlen / PARTS / kBlockEntries + 1 + static_cast<uint64_t>(parts) * kWaves * kRunBlocks;
+    // windows <= bytes/2; a uniform sample sends ~0.45*bytes/16 entries to each queue.  Room for
+    // bytes/16 entries (2.2x) plus the run each wave may leave unfinished.
+    uint64_t cap = maxlen / kQueues / kBlockEntries + 1 + static_cast<uint64_t>(parts) * kWaves * kRunBlocks;
     cap = (cap + kRunBlocks - 1) / kRunBlocks * kRunBlocks;
     if (cap > 0xFFFFFFFFull - kRunBlocks) return VK_EINVAL;
-    const size_t per_sample = static_cast<size_t>(PARTS) * cap * 128u;
+    const size_t per_sample = static_cast<size_t>(kQueues) * cap * 128u;
     uint32_t batch = static_cast<uint32_t>(ctx->spill_budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
-    const size_t cursor_bytes = (static_cast<size_t>(batch) * PARTS * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t cursor_bytes = (static_cast<size_t>(batch) * kQueues * sizeof(uint32_t) + 255) / 256 * 256;
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap, cursor_bytes + batch * per_sample);
     if (rc) return rc;
     BucketParams bp;
@@ -1049,16 +1065,16 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     bp.cap_blocks = static_cast<uint32_t>(cap);
     VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
     ctx->last_block = kCountThreads;
-    ctx->last_lds = kWaves * kPiece + 2 * 66 * 16 + kWaves * kQueueEntries * 2 + 3 * kWaves * 16 * 4;
+    ctx->last_lds = kWaves * kPiece + 2 * 66 * 16 + kWaves * kQueues * kQueueCap * 2 + 3 * kWaves * kQueues * 4;
     for (uint32_t s0 = 0; s0 < nsamples; s0 += batch) {
         const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
-        VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * PARTS * sizeof(uint32_t), ctx->stream));
+        VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * kQueues * sizeof(uint32_t), ctx->stream));
         ctx->last_grid = n * parts;
         hipLaunchKernelGGL((vk_bucket_kernel<K>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
                            ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp);
         VK_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * PARTS), dim3(kCountThreads), 0, ctx->stream, bp,
+        hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp,
                            d_hist + static_cast<size_t>(s0) * NCODE);
         VK_HIP(ctx, hipGetLastError());
     }

@@ -117,6 +117,15 @@ int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t np
                   uint32_t npix_out, const uint32_t* src0, const uint32_t* src1,
                   const uint8_t* w0, const uint8_t* w1, int sum_rc, uint8_t* img_out);
 
+/* Input side of `varKoder query` (commands/query.py:283-324 with the item transform of
+ * commands/train.py:236-245): uint8 images d_img[nimg][side*side] (device) -> float32
+ * d_out[nimg][3][out][out] = ((PIL BOX-resampled pixel)/255 - mean)/std, grey replicated to three
+ * channels.  bounds[out][2] = (first source index, count) and coef[out][kmax] = PIL's 22-bit
+ * fixed-point BOX coefficients of one axis (host tables, built by varkoder_amd/query.py). */
+int vk_preprocess_device(vk_ctx* ctx, const uint8_t* d_img, uint32_t nimg, uint32_t side,
+                         uint32_t out, const int32_t* bounds, const int32_t* coef, uint32_t kmax,
+                         float mean, float stdv, float* d_out);
+
 /* Introspection used by bench.py / tests: workgroups and LDS bytes of the last
  * vk_count_device launch. */
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes);

@@ -12,7 +12,7 @@ VK_ST_BAD_START, VK_ST_BAD_PHASE = 1, 2
 # every symbol include/vkimg.h declares
 SYMBOLS = ("vk_abi_version", "vk_strerror", "vk_last_hip_error", "vk_ctx_create", "vk_ctx_destroy",
            "vk_ctx_sync", "vk_set_mapping", "vk_count_device", "vk_image_device",
-           "vk_fastq_to_image_device", "vk_count_host", "vk_image_host", "vk_synth_fastq_device", "vk_remap_host",
+           "vk_fastq_to_image_device", "vk_count_host", "vk_image_host", "vk_synth_fastq_device", "vk_remap_host", "vk_preprocess_device",
            "vk_last_count_launch")
 
 _lib = None
@@ -50,6 +50,7 @@ def lib():
     L.vk_image_host.argtypes = [vp, u32p, C.c_int, u8p]
     L.vk_synth_fastq_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
     L.vk_last_count_launch.argtypes = [vp, u32p, u32p, u32p]
+    L.vk_preprocess_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, C.c_float, C.c_float, vp]
     L.vk_remap_host.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int, vp]
     for name in SYMBOLS:
         f = getattr(L, name)

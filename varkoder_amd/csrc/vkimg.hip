@@ -942,6 +942,42 @@ __global__ __launch_bounds__(256) void vk_remap_kernel(const uint8_t* __restrict
     }
 }
 
+// ------------------------------------------------------------ query preprocessing ----
+// fastai's inference-time item/batch transforms for a fixed-input-size timm model
+// (commands/train.py:236-245: Resize(squish, BOX) to the model's input size; IntToFloatTensor;
+// Normalize(mean, std)): PIL's 8-bit BOX resample = two separable passes with 22-bit fixed-point
+// coefficients and an 8-bit intermediate, then (v/255 - mean)/std in float32, grey replicated to
+// 3 channels.  One workgroup per image; the [side][out] intermediate lives in LDS.
+__global__ __launch_bounds__(256) void vk_preprocess_kernel(const uint8_t* __restrict__ img, uint32_t side,
+                                                             uint32_t out, const int32_t* __restrict__ bounds,
+                                                             const int32_t* __restrict__ coef, uint32_t kmax,
+                                                             float mean, float stdv, float* __restrict__ dst) {
+    extern __shared__ uint8_t tmp[];  // [side][out]
+    const uint8_t* src = img + static_cast<uint64_t>(blockIdx.x) * side * side;
+    float* o = dst + static_cast<uint64_t>(blockIdx.x) * 3u * out * out;
+    for (uint32_t i = threadIdx.x; i < side * out; i += blockDim.x) {
+        const uint32_t y = i / out, xx = i % out;
+        const int32_t x0 = bounds[2 * xx], n = bounds[2 * xx + 1];
+        int32_t ss = 1 << 21;
+        for (int32_t k = 0; k < n; ++k) ss += static_cast<int32_t>(src[y * side + x0 + k]) * coef[xx * kmax + k];
+        ss >>= 22;
+        tmp[i] = static_cast<uint8_t>(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < out * out; i += blockDim.x) {
+        const uint32_t yy = i / out, xx = i % out;
+        const int32_t y0 = bounds[2 * yy], n = bounds[2 * yy + 1];
+        int32_t ss = 1 << 21;
+        for (int32_t k = 0; k < n; ++k) ss += static_cast<int32_t>(tmp[(y0 + k) * out + xx]) * coef[yy * kmax + k];
+        ss >>= 22;
+        const float v = static_cast<float>(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+        const float f = (v / 255.0f - mean) / stdv;
+        o[i] = f;
+        o[out * out + i] = f;
+        o[2u * out * out + i] = f;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI ------
@@ -1335,6 +1371,35 @@ int vk_debug_read_stamps(unsigned long long* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vk_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
 #endif
+
+int vk_preprocess_device(vk_ctx* ctx, const uint8_t* d_img, uint32_t nimg, uint32_t side, uint32_t out,
+                         const int32_t* bounds, const int32_t* coef, uint32_t kmax, float mean, float stdv,
+                         float* d_out) {
+    if (!ctx || !d_img || !d_out || !bounds || !coef || side == 0 || out == 0 || kmax == 0 || stdv == 0.0f)
+        return VK_EINVAL;
+    if (static_cast<size_t>(side) * out > 160u * 1024u - 1024u) return VK_EINVAL;  // LDS intermediate
+    for (uint32_t i = 0; i < out; ++i) {
+        const int32_t x0 = bounds[2 * i], n = bounds[2 * i + 1];
+        if (x0 < 0 || n < 0 || static_cast<uint32_t>(n) > kmax || static_cast<uint32_t>(x0 + n) > side) return VK_EINVAL;
+    }
+    if (nimg == 0) return VK_OK;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t tb = static_cast<size_t>(out) * 2 * sizeof(int32_t), cb = static_cast<size_t>(out) * kmax * sizeof(int32_t);
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_stage), &ctx->stage_cap, tb + cb + 256);
+    if (rc) return rc;
+    int32_t* d_bounds = reinterpret_cast<int32_t*>(ctx->d_stage);
+    int32_t* d_coef = d_bounds + out * 2;
+    VK_HIP(ctx, hipMemcpyAsync(d_bounds, bounds, tb, hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d_coef, coef, cb, hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host tables may be temporaries
+    const size_t lds = static_cast<size_t>(side) * out;
+    VK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(vk_preprocess_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    hipLaunchKernelGGL(vk_preprocess_kernel, dim3(nimg), dim3(256), lds, ctx->stream, d_img, side, out, d_bounds,
+                       d_coef, kmax, mean, stdv, d_out);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
 
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes) {
     if (!ctx) return VK_EINVAL;

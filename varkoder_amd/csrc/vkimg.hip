@@ -1089,7 +1089,13 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     cap = (cap + kRunBlocks - 1) / kRunBlocks * kRunBlocks;
     if (cap > 0xFFFFFFFFull - kRunBlocks) return VK_EINVAL;
     const size_t per_sample = static_cast<size_t>(kQueues) * cap * 128u;
-    uint32_t batch = static_cast<uint32_t>(ctx->spill_budget / per_sample);
+    // never plan for more than three quarters of what is free (plus what this context already holds)
+    size_t free_b = 0, total_b = 0;
+    VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = ctx->spill_budget;
+    const size_t avail = free_b / 4 * 3 + ctx->spill_cap;
+    if (budget > avail) budget = avail;
+    uint32_t batch = static_cast<uint32_t>(budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
     const size_t cursor_bytes = (static_cast<size_t>(batch) * kQueues * sizeof(uint32_t) + 255) / 256 * 256;

@@ -188,9 +188,9 @@ __device__ __forceinline__ WaveRange wave_range(uint64_t len, uint32_t parts, ui
     return r;
 }
 
-// One wavefront streams the FASTQ bytes [w0, w1) of a sample and calls emit(raw_field << 2)
-// for every countable K-mer window (raw field: first base least significant, vk_lane.h);
-// after_group() runs after every 16 positions.  `st` is the wave's private 4 KiB LDS slot,
+// One wavefront streams the FASTQ bytes [w0, w1) of a sample and hands every 64-byte block's code
+// string and countable-window mask to windows(ch, C[4], ok[4]) (raw fields: first base least
+// significant, vk_lane.h).  `st` is the wave's private 4 KiB LDS slot,
 // below/above the shared mask tables.  Returns the line phase at w0 and at w1.
 // Window loop of the LDS-histogram kernels (K <= 7): same arithmetic as vkl::windows<K>, with the
 // predicated histogram update written out.  hipcc lowers `if (carry) atomicAdd(...)` to
@@ -273,11 +273,10 @@ __device__ unsigned long long g_vk_stamps[8];
     } while (0)
 #endif
 
-template <int K, bool LDS_HIST, typename Emit, typename Hook>
+template <int K, typename Windows>
 __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
                                             uint64_t w1, uint4* st, const uint4* below, const uint4* above,
-                                            int lane, Emit emit, Hook after_group, uint32_t& ph_start,
-                                            uint32_t& ph_end, uint32_t lds_hist_base = 0) {
+                                            int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end) {
     const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(st), lane) : 0u;
     ph_start = ph0;
 
@@ -362,8 +361,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         vkl::ok_mask<K>(badh, bad, ok);
         if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
         VK_STAMP(t3);
-        if constexpr (LDS_HIST) windows_lds<K>(ch, lb.C, ok, lds_hist_base);
-        else vkl::windows<K>(ch, lb.C, ok, emit, after_group);
+        windows(ch, lb.C, ok);  // the consumer's window stage (LDS histogram or bucket queues)
         pph += total;
 #ifdef VK_STAMPS
         VK_STAMP(t4);
@@ -419,13 +417,12 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const WaveRange wr = wave_range(len, parts, part, wave);
     uint32_t ph_start = 0, ph_end = 0;
     if (!wr.empty) {
-        auto emit = [&](uint32_t a4) {  // a4 = raw field << 2 = byte offset into the histogram
-            atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + a4), 1u);
-        };
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
-        wave_stream<K, true>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, [] {}, ph_start, ph_end,
-                             hist_base);
+        auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
+            windows_lds<K>(ch, C, ok, hist_base);
+        };
+        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
@@ -584,8 +581,10 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             const uint32_t nb = n / kBlockEntries;
             if (__any(nb != 0u)) drain_all(n, nb);
         };
-        wave_stream<K, false>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, emit, after_group, ph_start,
-                              ph_end);
+        auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
+            vkl::windows<K>(ch, C, ok, emit, after_group);
+        };
+        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end);
         // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();
         uint32_t n = qcnt[wave][q];

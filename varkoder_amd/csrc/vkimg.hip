@@ -15,15 +15,16 @@
 //     wave streams its own contiguous byte range in 4 KiB pieces (4 coalesced
 //     16-B loads per lane, prefetched one piece ahead), transposes the piece
 //     through a private 4 KiB LDS slot so that each lane owns 64 contiguous
-//     bytes, and walks those bytes from registers;
+//     bytes, and classifies them with 32-bit SWAR arithmetic (vk_lane.h);
 //   * FASTQ line phase (header/sequence/plus/quality) comes from a wave-level
 //     prefix sum of newline counts; the phase at a range start is recovered
 //     locally from the '@' / '+' framing, so byte ranges are independent;
 //   * k-mer windows are counted forward-strand only into an LDS histogram
 //     (ds_add_u32); the strand merge happens once per sample in K2;
 //   * 4^k u32 > LDS for k = 8, 9: windows are bucketed through wave-private LDS queues into
-//     per-part streams in HBM and replayed into 16384-bin LDS histograms (vk_bucket_kernel,
+//     16 streams per sample in HBM and replayed into 4^k/16-bin LDS histograms (vk_bucket_kernel,
 //     vk_bucket_count_kernel).
+//   vk_remap_kernel / vk_preprocess_kernel: `convert`'s remap and the input side of `query`.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -161,3 +161,52 @@ def test_cli_image_on_an_intermediate_folder(tmp_path):
         cli.main(["image", str(tmp_path / "int"), "-o", str(out), "-f", str(stats)])
     with pytest.raises(ValueError, match="between 5 and 9"):
         cli.main(["image", str(tmp_path / "int"), "-k", "4", "-o", str(tmp_path / "o2")])
+
+
+def test_abi_argument_errors(engines):
+    """Status codes, never crashes: unaligned sample offsets, missing mapping, bad k."""
+    import ctypes as C
+    import torch
+    from varkoder_amd import _capi
+    eng = engines(7)
+    L = eng.L
+    fq = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(4 ** 7, dtype=torch.int32, device="cuda")
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    offs, lens = (C.c_uint64 * 1)(8), (C.c_uint64 * 1)(100)          # offset not a multiple of 16
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    assert L.vk_count_device(eng.ctx, vp(fq), offs, lens, 1, 7, 0, vp(hist), vp(st)) == _capi.VK_EINVAL
+    offs[0] = 0
+    assert L.vk_count_device(eng.ctx, vp(fq), offs, lens, 1, 4, 0, vp(hist), vp(st)) == _capi.VK_EINVAL
+    assert L.vk_count_device(eng.ctx, vp(fq), offs, lens, 0, 7, 0, vp(hist), vp(st)) == _capi.VK_OK   # empty batch
+    ctx = C.c_void_p()
+    assert L.vk_ctx_create(0, None, 1, C.byref(ctx)) == _capi.VK_OK
+    img = torch.zeros(128 * 128, dtype=torch.uint8, device="cuda")
+    assert L.vk_image_device(ctx, vp(hist), 1, 7, vp(img)) == _capi.VK_ENOMAP        # no vk_set_mapping yet
+    assert L.vk_set_mapping(ctx, 7, None, 100) == _capi.VK_EINVAL                    # cgr needs npix = 4^k
+    L.vk_ctx_destroy(ctx)
+    with pytest.raises(_capi.VkError, match="invalid argument"):
+        _capi.check(eng.ctx, _capi.VK_EINVAL, "demo")
+
+
+def test_bench_script_runs_end_to_end(tmp_path):
+    """bench.py with a tiny workload: the JSON contract fields are all there."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Gbases/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None
+    assert d["bad_status_samples"] == 0 and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert "workload" in d["config"]

@@ -90,3 +90,25 @@ def test_missing_library_is_an_error(monkeypatch):
     monkeypatch.setattr(_capi, "LIB_PATH", os.path.join(os.path.dirname(_capi.LIB_PATH), "nope.so"))
     with pytest.raises(_capi.VkError, match="no CPU fallback"):
         _capi.lib()
+
+
+def test_dsk_text_dump_roundtrip():
+    """dsk2ascii-style text: one line per canonical class, parses back to the class
+    totals whichever spelling convention is printed."""
+    import vectors
+    from varkoder_amd import formats
+    for k in (5, 6):
+        fwd = vectors.fwd_hist(k, "heavy")
+        want = vectors.class_totals(fwd, k).astype(np.uint64)
+        for conv in ("gatb", "lex"):
+            text = formats.dsk_text(fwd, k, conv)
+            lines = text.splitlines()
+            rc = vectors.revcomp_codes(k)
+            nclasses = int(((np.arange(4 ** k) <= rc) & (want > 0)).sum())
+            assert len(lines) == nclasses
+            assert all(len(ln.split(" ")[0]) == k for ln in lines[:50])
+            assert np.array_equal(formats.parse_dsk_text(text, k), want)
+    # GATB order A<C<T<G: of {ACG.., CGT..} style pairs the printed spelling can differ from lex
+    t = formats.dsk_text(np.eye(1, 4 ** 5, mapping.codes_of(["GGGGA"])[0], dtype=np.uint32)[0], 5, "gatb")
+    assert t in ("GGGGA 1\n", "TCCCC 1\n") and t == "TCCCC 1\n"      # T < G in GATB's order
+    assert formats.dsk_text(np.eye(1, 4 ** 5, mapping.codes_of(["GGGGA"])[0], dtype=np.uint32)[0], 5, "lex") == "GGGGA 1\n"

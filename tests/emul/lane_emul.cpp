@@ -22,17 +22,31 @@ uint32_t pair_reverse(uint32_t c, int k) {
     return r;
 }
 
-// csrc/vkimg.hip sync_phase(), scalar
-uint32_t sync_phase(const uint8_t* s, uint64_t w0, uint64_t len) {
+// csrc/vkimg.hip sync_rule() / sync_phase(), scalar
+uint32_t sync_rule(const uint8_t* s, uint64_t at, uint64_t len) {
     uint64_t nl[6];
     uint32_t n = 0;
-    for (uint64_t p = w0; p < len && n < 6; ++p)
+    for (uint64_t p = at; p < len && n < 6; ++p)
         if (s[p] == '\n') nl[n++] = p;
     for (uint32_t i = 0; i + 2 < n && i < 4; ++i) {
         uint64_t li = nl[i] + 1, lj = nl[i + 2] + 1;
         if (lj < len && s[li] == '@' && s[lj] == '+') return (3u - i) & 3u;
     }
+    return 4u;
+}
+
+uint32_t sync_phase(const uint8_t* s, uint64_t w0, uint64_t len) {
+    uint32_t ph = sync_rule(s, w0, len);
+    if (ph < 4u) return ph;
+    const uint64_t back = w0 > 65536 ? w0 - 65536 : 0;
     uint32_t cnt = 0;
+    if (back != 0) {
+        ph = sync_rule(s, back, len);
+        if (ph < 4u) {
+            for (uint64_t p = back; p < w0; ++p) cnt += s[p] == '\n';
+            return (ph + cnt) & 3u;
+        }
+    }
     for (uint64_t p = 0; p < w0; ++p) cnt += s[p] == '\n';
     return cnt & 3u;
 }

@@ -119,9 +119,11 @@ __device__ __forceinline__ uint4 load_granule(const uint8_t* sbase, uint64_t off
 // start with '@', but then l_{i+2} is a sequence line, which never starts with '+').
 // Falls back to counting the newlines of [0, w0) when fewer than six newlines
 // follow w0.  Wave-uniform; `slot` is this wave's private LDS scratch.
-__device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, uint64_t* slot, int lane) {
+// The '@' / '+' rule at byte position `at`: phase of the line holding `at`, or 4 if fewer than
+// the needed newlines follow.
+__device__ uint32_t sync_rule(const uint8_t* sbase, uint64_t at, uint64_t len, uint64_t* slot, int lane) {
     uint32_t n = 0;
-    uint64_t pos = w0;
+    uint64_t pos = at;
     while (n < 6 && pos < len) {
         uint8_t b = (pos + lane < len) ? sbase[pos + lane] : 0;
         unsigned long long m = __ballot(b == '\n');
@@ -134,21 +136,40 @@ __device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, 
         pos += 64;
     }
     wave_lds_fence();
+    uint32_t ph = 4u;
     for (uint32_t i = 0; i + 2 < n && i < 4; ++i) {
         uint64_t li = slot[i] + 1, lj = slot[i + 2] + 1;
         if (lj < len && sbase[li] == '@' && sbase[lj] == '+') {
-            wave_lds_fence();
-            return (3u - i) & 3u;  // the line holding w0 is line -1: phase (-1 - i) mod 4
+            ph = (3u - i) & 3u;  // the line holding `at` is line -1: phase (-1 - i) mod 4
+            break;
         }
     }
     wave_lds_fence();
-    // slow, always-correct path: count newlines before w0 (w0 is a multiple of 64)
+    return ph;
+}
+
+// newlines in [from, to), both multiples of 16, counted by the whole wave
+__device__ uint32_t count_newlines(const uint8_t* sbase, uint64_t from, uint64_t to, int lane) {
     uint32_t cnt = 0;
-    for (uint64_t off = static_cast<uint64_t>(lane) * 16; off + 16 <= w0; off += 1024)
+    for (uint64_t off = from + static_cast<uint64_t>(lane) * 16; off + 16 <= to; off += 1024)
         cnt += nl_count16(*reinterpret_cast<const uint4*>(sbase + off));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-    return cnt & 3u;
+    return cnt;
+}
+
+__device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, uint64_t* slot, int lane) {
+    uint32_t ph = sync_rule(sbase, w0, len, slot, lane);
+    if (ph < 4u) return ph;
+    // Too few lines after w0 (a range at the very end of a sample): apply the rule 64 KiB earlier and
+    // count the newlines in between; only a sample with lines longer than that falls through to
+    // counting every newline before w0.
+    const uint64_t back = w0 > 65536 ? w0 - 65536 : 0;
+    if (back != 0) {
+        ph = sync_rule(sbase, back, len, slot, lane);
+        if (ph < 4u) return (ph + count_newlines(sbase, back, w0, lane)) & 3u;
+    }
+    return count_newlines(sbase, 0, w0, lane) & 3u;
 }
 
 // --------------------------------------------------------------- K1 count ----

@@ -210,3 +210,30 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert "workload" in d["config"]
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/fastq_to_pgm.c: the shared library used from C without Python or PyTorch in the
+    process; its image equals the oracle's."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = tmp_path / "fastq_to_pgm"
+    libdir = os.path.join(root, "varkoder_amd")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fastq_to_pgm.c"), "-o", str(exe), "-L", libdir,
+                           "-l:libvkimg_hip.so", f"-Wl,-rpath,{libdir}"])
+    fq = tmp_path / "s.fq"
+    data = _write_fastq(fq, 77, 5000)
+    out = tmp_path / "s.pgm"
+    res = subprocess.run([str(exe), str(fq), "7", str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    raw = out.read_bytes()
+    assert raw.startswith(b"P5\n128 128\n255\n")
+    got = np.frombuffer(raw[len(b"P5\n128 128\n255\n"):], dtype=np.uint8)
+    want, nwin, st = oracle.fastq_to_image(data, 7, pixel_lut(7, "cgr"), 128 * 128)
+    assert st == 0 and np.array_equal(got, want)
+    assert f"{nwin} k-mer windows" in res.stdout

@@ -46,7 +46,7 @@ extern "C" {
 #define VK_ENOMEM 5
 
 /* per-sample status bits written by the count stage */
-#define VK_ST_BAD_START 1u     /* first byte of a non-empty sample is not '@' */
+#define VK_ST_BAD_START 1u     /* first record malformed: no leading '@', or third line not '+' */
 #define VK_ST_BAD_PHASE 2u     /* line count mod 4 inconsistent between byte ranges / at EOF */
 
 typedef struct vk_ctx vk_ctx;

@@ -60,6 +60,15 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
     const uint64_t bw = (bwg + kWaves - 1) / kWaves;
     uint32_t st = 0, prev_end = 0;
     if (len && s[0] != '@') st |= 1u;
+    {
+        uint32_t seen = 0;
+        const uint64_t lim = len < 65536 ? len : 65536;
+        for (uint64_t p = 0; p < lim; ++p)
+            if (s[p] == '\n' && ++seen == 2) {
+                if (p + 1 < len && s[p + 1] != '+') st |= 1u;
+                break;
+            }
+    }
     for (uint32_t part = 0; part < parts; ++part)
         for (int wave = 0; wave < kWaves; ++wave) {
             uint64_t blk0 = (uint64_t)part * bwg + (uint64_t)wave * bw;

@@ -107,6 +107,12 @@ def test_bad_framing_sets_status(engines):
     assert st & 2
     _, st = eng.count_host(good)
     assert st == 0
+    # wrapped (multi-line) FASTQ: 6 lines per record can look consistent mod 4; the first record gives it away
+    wrapped = b"".join(b"@r%d\nACGTACGTAC\nGGGTTTAAAC\n+\nIIIIIIIIII\nIIIIIIIIII\n" % i for i in range(40))
+    _, st = eng.count_host(wrapped)
+    assert st & 1
+    _, st = eng.count_host(b">seq1\nACGTACGTACGTACGT\n>seq2\nACGTACGTAAAA\n")        # FASTA
+    assert st & 1
 
 
 @pytest.mark.parametrize("k,mapping", [(7, "varKode"), (9, "cgr")])

@@ -63,6 +63,8 @@ def test_emulated_wave_flags_bad_framing(emul):
     assert emul(good, 7, 1)[1] == 0
     assert emul(good[1:], 7, 1)[1] & 1
     assert emul(good[:-200], 7, 2)[1] & 2
+    wrapped = b"".join(b"@r%d\nACGTACGTAC\nGGGTTTAAAC\n+\nIIIIIIIIII\nIIIIIIIIII\n" % i for i in range(40))
+    assert emul(wrapped, 7, 1)[1] & 1
 
 
 def test_emulated_wave_fuzz(emul):

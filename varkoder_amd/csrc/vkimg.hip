@@ -673,6 +673,16 @@ __global__ void vk_check_kernel(const uint8_t* __restrict__ fastq, const uint64_
     if (len) {
         const uint8_t* sbase = fastq + offs[s];
         if (sbase[0] != '@') st |= VK_ST_BAD_START;
+        // the third line of the first record must be the '+' line: catches FASTA and wrapped
+        // (multi-line) FASTQ, whose line counts could otherwise look consistent by accident
+        uint32_t seen = 0;
+        const uint64_t lim = len < 65536 ? len : 65536;
+        for (uint64_t p = 0; p < lim; ++p) {
+            if (sbase[p] == '\n' && ++seen == 2) {
+                if (p + 1 < len && sbase[p + 1] != '+') st |= VK_ST_BAD_START;
+                break;
+            }
+        }
         uint32_t prev = 0;  // phase at byte 0
         const uint32_t* wp = wavephase + static_cast<uint64_t>(s) * parts * kWaves;
         for (uint32_t i = 0; i < parts * kWaves; ++i) {

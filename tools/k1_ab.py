@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""A/B timing of experimental builds of the count kernel: python tools/k1_ab.py lib1.so lib2.so ...
+Each library runs in its own child process (one ctypes load per process).  Prints the K1 launch
+time for 1000 samples x 1M x 150 bp (pool of 64 distinct samples), k=7, and checks the histogram of
+sample 0 against the default build's."""
+import subprocess
+import sys
+
+CHILD = r"""
+import sys, time, hashlib
+sys.path.insert(0, ".")
+import numpy as np, torch
+from varkoder_amd import _capi
+if sys.argv[1] != "default":
+    _capi.LIB_PATH = sys.argv[1]
+from varkoder_amd.engine import ImageEngine
+k = int(sys.argv[2]); samples = int(sys.argv[3]); dist = int(sys.argv[4])
+eng = ImageEngine(k=k, mapping="cgr")
+fq, po, pl = eng.synth(0, 64, 1_000_000, 150, dist=dist)
+idx = np.arange(samples) % 64
+offs, lens = po[idx].copy(), pl[idx].copy()
+hist = torch.empty((samples, 4 ** k), dtype=torch.int32, device="cuda")
+status = torch.empty((samples,), dtype=torch.int32, device="cuda")
+eng.count(fq, offs, lens, hist=hist, status=status); torch.cuda.synchronize()
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); eng.count(fq, offs, lens, hist=hist, status=status); torch.cuda.synchronize()
+    ts.append(time.perf_counter() - t0)
+h = hashlib.sha256(hist[:64].cpu().numpy().tobytes()).hexdigest()[:16]
+print(f"{sys.argv[1]:40s} k={k} dist={dist} K1 {min(ts)*1e3:8.2f} ms (min of 3; {[round(t*1e3,1) for t in ts]}) bad={int((status!=0).sum())} sha={h}", flush=True)
+"""
+
+if __name__ == "__main__":
+    libs = [a for a in sys.argv[1:] if not a.startswith("--")]
+    k = 7
+    samples = 1000
+    dist = 0
+    for a in sys.argv[1:]:
+        if a.startswith("--k="): k = int(a[4:])
+        if a.startswith("--samples="): samples = int(a[10:])
+        if a.startswith("--dist="): dist = int(a[7:])
+    rc = 0
+    for lib in ["default"] + libs:
+        r = subprocess.run([sys.executable, "-c", CHILD, lib, str(k), str(samples), str(dist)])
+        rc |= r.returncode
+    sys.exit(rc)

@@ -152,7 +152,7 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
         const uint32_t p23l = perm(a3, a2, 0x05010400u), p23h = perm(a3, a2, 0x07030602u);
         const uint32_t T[4] = {perm(p23l, p01l, 0x05040100u), perm(p23l, p01l, 0x07060302u),
                                perm(p23h, p01h, 0x05040100u), perm(p23h, p01h, 0x07060302u)};
-        uint32_t C = 0, IV = 0, NN = 0;
+        uint32_t C = 0, IV = 0, NL = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -162,19 +162,24 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
             const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
             const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
             C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
-            // bit 7 := byte is not a base: some bit of x & 0x7C set (carry trick), or bit 7 of x
-            uint32_t nz = (x & 0x7C7C7C7Cu) + k7f;
-            if (!ASCII) nz |= x;
+            uint32_t nz, eq;
+            if (ASCII) {
+                // every byte of t and x is below 0x80, so plain byte-wise adds cannot carry out:
+                nz = x + 0x7C7C7C7Cu;                             // bit 7 := x >= 4 (not a base)
+                eq = xor_add_k(t, 0x75757575u, 0x01010101u);      // bit 7 := t == '\n' (0x0A ^ 0x75 = 0x7F)
+            } else {
+                // bit 7 := some bit of x & 0x7C set (carry trick), or bit 7 of x
+                nz = ((x & 0x7C7C7C7Cu) + k7f) | x;
+                // bit 7 := low 7 bits equal 0x0A and bit 7 of t clear
+                eq = ~(xor_add_k(t & k7f, 0x0A0A0A0Au, k7f) | t);
+            }
             IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
-            // bit 7 := byte is not '\n': low 7 bits differ from 0x0A, or bit 7 of t
-            uint32_t nn = xor_add_k(t & k7f, 0x0A0A0A0Au, k7f);
-            if (!ASCII) nn |= t;
-            NN = and_or_k(nn >> (7 - 2 * j), 0x01010101u << (2 * j), NN);
+            NL = and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
         }
         o.C[g] = C;
         o.IV[g] = IV;
-        o.NL[g] = ~NN & 0x55555555u;
-        c += popc(o.NL[g]);
+        o.NL[g] = NL;
+        c += popc(NL);
     }
     return c;
 }

@@ -91,6 +91,19 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     return out
 
 
+def dsk_argv(threads, k, infile, tmpdir, outpath):
+    """The reference's dsk command line (commands/image.py:771-790; pinned by tests/golden tool_argv)."""
+    return ["dsk", "-nb-cores", str(threads), "-kmer-size", str(k), "-abundance-min", "1",
+            "-abundance-min-threshold", "1", "-max-memory", "1000", "-file", str(infile), "-out-tmp", str(tmpdir),
+            "-out", str(outpath)]
+
+
+def dsk2ascii_argv(threads, counts, tmpdir):
+    """The reference's dsk2ascii command line (commands/image.py:875-891)."""
+    return ["dsk2ascii", "-c", "-file", str(counts), "-nb-cores", str(threads), "-out",
+            os.path.join(str(tmpdir), "dsk.txt"), "-verbose", "0"]
+
+
 def dsk_reference(buf, args, cores):
     """If GATB dsk is on PATH (it is not in the build image), time the reference's exact
     invocation (varKoder/commands/image.py:771-790, :875-886) on one sample of the workload."""
@@ -106,12 +119,9 @@ def dsk_reference(buf, args, cores):
         for nc in (1, cores):
             h5 = os.path.join(tmp, f"s_{nc}.h5")
             t0 = time.perf_counter()
-            subprocess.run(["dsk", "-nb-cores", str(nc), "-kmer-size", str(args.k), "-abundance-min", "1",
-                            "-abundance-min-threshold", "1", "-max-memory", "1000", "-file", fq, "-out-tmp", tmp,
-                            "-out", h5], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            subprocess.run(["dsk2ascii", "-c", "-file", h5, "-nb-cores", str(nc), "-out",
-                            os.path.join(tmp, "dsk.txt"), "-verbose", "0"], stdout=subprocess.DEVNULL,
+            subprocess.run(dsk_argv(nc, args.k, fq, tmp, h5), check=True, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL)
+            subprocess.run(dsk2ascii_argv(nc, h5, tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             res[f"gbases_per_s_{nc}_cores"] = args.reads * args.readlen / (time.perf_counter() - t0) / 1e9
         res["kind"] = "reference (dsk + dsk2ascii, one sample)"
         return res

@@ -79,3 +79,25 @@ def fake_dsk2ascii_on_path():
         os.chmod(p, os.stat(p).st_mode | stat.S_IEXEC)
         os.environ["PATH"] = _FAKE_DIR + os.pathsep + os.environ["PATH"]
     return _FAKE_DIR
+
+
+def recording_tools_on_path(log_path):
+    """Put `dsk` and `dsk2ascii` stand-ins first on PATH that append their argv (one JSON list per
+    line) to log_path; `dsk` then creates its -out file, `dsk2ascii` cats its -file argument."""
+    d = tempfile.mkdtemp(prefix="recdsk_")
+    body = ('#!/usr/bin/env python3\nimport json, sys\n'
+            'with open(%r, "a") as f:\n    f.write(json.dumps([%%r] + sys.argv[1:]) + "\\n")\n'
+            'a = sys.argv[1:]\n' % log_path)
+    tails = {"dsk": 'open(a[a.index("-out") + 1], "w").close()\n',
+             "dsk2ascii": 'sys.stdout.write(open(a[a.index("-file") + 1]).read())\n'}
+    for name, tail in tails.items():
+        p = os.path.join(d, name)
+        with open(p, "w") as f:
+            f.write(body % name + tail)
+        os.chmod(p, os.stat(p).st_mode | stat.S_IEXEC)
+    os.environ["PATH"] = d + os.pathsep + os.environ["PATH"]
+    return d
+
+
+def drop_from_path(d):
+    os.environ["PATH"] = os.pathsep.join(x for x in os.environ["PATH"].split(os.pathsep) if x != d)

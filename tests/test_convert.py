@@ -90,3 +90,64 @@ def test_remap_kernel_on_docs_images():
         assert np.array_equal(np.array(convert.remap(Image.fromarray(vk), 7, "varKode", "cgr")), cg)
     with pytest.raises(Exception, match="Input and output mapping must be one of"):
         convert.remap_array(np.zeros((32, 32), np.uint8), 5, "cgr", "nope")
+
+
+# ---- folder-level `convert` (commands/convert.py:80-202) -----------------------------------
+
+def _lay_out_docs(manifest, root):
+    """Recreate the golden run's input tree from the committed docs images."""
+    import shutil
+    for name, rel in manifest["convert_command"]["layout"].items():
+        src = os.path.join(GOLDEN, "docs_" + name.split(":")[-1])
+        dst = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(src, dst)
+
+
+def test_filename_metadata_cases(manifest):
+    from varkoder_amd.convert import get_metadata_from_img_filename
+    for case in manifest["filename_metadata_cases"]:
+        if "raises" in case:
+            with pytest.raises(ValueError):
+                get_metadata_from_img_filename(case["name"])
+        else:
+            md = get_metadata_from_img_filename(case["name"])
+            md["path"] = str(md["path"])
+            assert md == case["metadata"], case["name"]
+
+
+def test_conversion_plan_follows_the_reference_path_rules(manifest, tmp_path, monkeypatch):
+    from varkoder_amd.convert import plan_conversion
+    _lay_out_docs(manifest, tmp_path)
+    monkeypatch.chdir(tmp_path)
+    for outdir, run in manifest["convert_command"]["outputs"].items():
+        plan = plan_conversion(run["input"], outdir, run["output_mapping"], run["input_mapping"],
+                               manifest["convert_command"]["kmer_size_arg"])
+        todo = sorted(str(md["outfile_path"].relative_to(outdir)) for md in plan
+                      if md["img_kmer_mapping"] != run["output_mapping"])
+        assert todo == sorted(run["files"]), outdir
+
+
+@pytest.mark.gpu
+def test_convert_command_matches_the_reference_run(manifest, tmp_path, monkeypatch):
+    from PIL import Image
+    from varkoder_amd import cli
+    _lay_out_docs(manifest, tmp_path)
+    monkeypatch.chdir(tmp_path)
+    for outdir, run in manifest["convert_command"]["outputs"].items():
+        argv = ["convert", "-k", str(manifest["convert_command"]["kmer_size_arg"])]
+        if run["sum_rc"]:
+            argv.append("-r")
+        if run["input_mapping"]:
+            argv += ["-p", run["input_mapping"]]
+        cli.main(argv + [run["output_mapping"], run["input"], outdir])
+        got = sorted(str(p.relative_to(tmp_path / outdir)) for p in (tmp_path / outdir).rglob("*.png"))
+        assert got == sorted(run["files"]), outdir
+        for rel, want in run["files"].items():
+            im = Image.open(tmp_path / outdir / rel)
+            a = np.array(im)
+            assert list(a.shape) == want["shape"] and a.dtype == np.uint8
+            assert hashlib.sha256(a.tobytes()).hexdigest() == want["sha256"], (outdir, rel)
+            assert {k: v for k, v in im.info.items() if isinstance(v, str)} == want["info"]
+    with pytest.raises(Exception, match="Output directory exists"):
+        cli.main(["convert", "varKode", "in", next(iter(manifest["convert_command"]["outputs"]))])

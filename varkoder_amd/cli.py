@@ -1,4 +1,5 @@
-"""`python -m varkoder_amd image ...`: steps D+E of `varKoder image` on the GPU.
+"""`python -m varkoder_amd image ...`: steps D+E of `varKoder image` on the GPU
+(`python -m varkoder_amd convert ...`: `varKoder convert`, see convert.convert_folder).
 
 Same flags as the reference's `image` sub-command (varKoder/cli.py:69-166).  Steps B/C of
 the reference (fastp cleaning, reformat.sh subsampling) are external CPU tools outside this
@@ -48,7 +49,31 @@ def setup_parser():
     p.add_argument("-X", "--no-image", action="store_true", help="nothing to do here without images")
     p.add_argument("-T", "--trim-bp", default="10,10", help="upstream (fastp) option; accepted for parity")
     p.add_argument("--labels-csv", help="optional CSV `sample,labels` (labels separated by ';')")
+    c = sub.add_parser("convert", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                       help="Convert images between different kmer mappings.")          # cli.py:447-482
+    c.add_argument("-R", "--seed", type=int, help="accepted for parity")
+    c.add_argument("-x", "--overwrite", action="store_true", help="overwrite existing results.")
+    c.add_argument("-v", "--verbose", action="store_true", default=False)
+    c.add_argument("-n", "--n-threads", type=int, default=1, help="host threads for reading / writing PNG files")
+    c.add_argument("-k", "--kmer-size", type=int, default=DEFAULT_KMER_SIZE, choices=[5, 6, 7, 8, 9],
+                   help="size of kmers used to produce original images (as in the reference, this value "
+                        "takes priority over the file names)")
+    c.add_argument("-p", "--input-mapping", choices=MAPPING_CHOICES,
+                   help="kmer mapping of input images. Will be inferred from file names if omitted.")
+    c.add_argument("-r", "--sum-reverse-complements", action="store_true",
+                   help="When converting from CGR to varKode, add together counts from canonical kmers and "
+                        "their reverse complements.")
+    c.add_argument("output_mapping", choices=MAPPING_CHOICES, help="kmer mapping of output images.")
+    c.add_argument("input", help="path to folder with png images files to be converted.")
+    c.add_argument("outdir", help="path to the folder where results will be saved.")
     return main
+
+
+def run_convert(args):
+    from .convert import convert_folder
+    n = convert_folder(args.input, args.outdir, args.output_mapping, args.input_mapping, args.kmer_size,
+                       args.sum_reverse_complements, args.overwrite, max(1, args.n_threads))
+    eprint(f"Converted {n} images; written to {args.outdir}")
 
 
 def read_labels(path):
@@ -122,8 +147,13 @@ def run_image(args):
 
 def main(argv=None):
     args = setup_parser().parse_args(argv)
+    if not Path(args.input).exists():                                       # cli.py:503-505
+        raise Exception("Input path", args.input, "does not exist. Please check.")
     if args.command == "image":
         run_image(args)
+    elif args.command == "convert":
+        run_convert(args)
+    eprint("DONE")
 
 
 if __name__ == "__main__":

@@ -93,3 +93,93 @@ def remap(img, k, in_mapping, out_mapping, sum_rc=False):
     """Drop-in for convert.py:34-77: PIL image in, PIL image out."""
     from PIL import Image
     return Image.fromarray(remap_array(np.array(img), k, in_mapping, out_mapping, sum_rc))
+
+
+# ---- the `convert` command at folder level (commands/convert.py:80-202) -----------------------
+
+def get_metadata_from_img_filename(img_path):
+    """`<sample>@<bp>K+<mapping>+k<k>.png` -> dict (core/utils.py:123-147); a legacy two-field
+    name `<sample>@<bp>K+k<k>.png` means mapping 'varKode'.  Raises ValueError on anything else."""
+    from pathlib import Path
+
+    from .config import BP_KMER_SEP, SAMPLE_BP_SEP
+    sample_name, rest = Path(img_path).name.removesuffix(".png").split(SAMPLE_BP_SEP)
+    fields = rest.split(BP_KMER_SEP)
+    if len(fields) == 3:
+        n_bp, mapping, ksize = fields
+    else:
+        n_bp, ksize = fields          # ValueError unless exactly two
+        mapping = "varKode"
+    return {"sample": sample_name, "bp": int(n_bp[:-1]) * 1000, "img_kmer_mapping": mapping,
+            "img_kmer_size": int(ksize[1:]), "path": Path(img_path)}
+
+
+def plan_conversion(input_dir, outdir, output_mapping, input_mapping=None, kmer_size=None):
+    """One record per *.png under input_dir with the reference's naming rules
+    (ConvertCommand._collect_image_files, convert.py:135-176), kept as they are:
+    -p / -k given on the command line override what the file name says; the output keeps the
+    sub-folders of the input minus the first level; a file whose name does not parse keeps its
+    path minus its first component."""
+    from pathlib import Path
+
+    from .config import BP_KMER_SEP, SAMPLE_BP_SEP
+    records = []
+    for f in Path(input_dir).rglob("*.png"):
+        try:
+            md = get_metadata_from_img_filename(f)
+            if input_mapping:
+                md["img_kmer_mapping"] = input_mapping
+            if kmer_size:
+                md["img_kmer_size"] = kmer_size
+        except Exception:  # noqa: BLE001 - as the reference: any parse failure
+            md = {"sample": None, "bp": None, "img_kmer_mapping": input_mapping, "img_kmer_size": kmer_size, "path": f}
+        if md["sample"] and md["bp"]:
+            fname = (f"{md['sample']}{SAMPLE_BP_SEP}{int(md['bp'] / 1000):08d}K{BP_KMER_SEP}"
+                     f"{output_mapping}{BP_KMER_SEP}k{md['img_kmer_size']}.png")
+            md["outfile_path"] = Path(outdir) / Path(*f.relative_to(Path(input_dir)).parent.parts[1:]) / fname
+        else:
+            md["outfile_path"] = Path(outdir) / Path(*f.parts[1:])
+        records.append(md)
+    return records
+
+
+def convert_folder(input_dir, outdir, output_mapping, input_mapping=None, kmer_size=None, sum_rc=False,
+                   overwrite=False, io_threads=8):
+    """`varKoder convert` for a folder of images: all images of one (k, input mapping) go through
+    ONE vk_remap_host call; PNG text chunks are carried over with `varkoderMapping` updated when
+    present (convert.py:108-121).  Returns the number of images written."""
+    import os
+    from collections import defaultdict
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+
+    from PIL import Image
+    from PIL.PngImagePlugin import PngInfo
+    if not overwrite and Path(outdir).exists():
+        raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
+    groups = defaultdict(list)
+    for md in plan_conversion(input_dir, outdir, output_mapping, input_mapping, kmer_size):
+        if md["img_kmer_mapping"] == output_mapping:
+            continue                                                     # convert.py:88-89
+        if os.path.exists(md["outfile_path"]) and not os.access(md["outfile_path"], os.W_OK):
+            continue                                                     # convert.py:92-93
+        groups[(md["img_kmer_size"], md["img_kmer_mapping"])].append(md)
+
+    def save(md, arr, info):
+        chunks = PngInfo()
+        for key, value in info.items():
+            chunks.add_text(key, output_mapping if key == "varkoderMapping" else str(value))
+        md["outfile_path"].parent.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(arr).save(md["outfile_path"], optimize=True, pnginfo=chunks)
+
+    written = 0
+    with ThreadPoolExecutor(io_threads) as pool:
+        for (k, in_mapping), mds in groups.items():
+            if (in_mapping not in MAPPING_CHOICES) or (output_mapping not in MAPPING_CHOICES):
+                raise Exception("Input and output mapping must be one of: " + str(MAPPING_CHOICES))
+            opened = list(pool.map(lambda md: Image.open(md["path"]), mds))
+            batch = np.stack([np.array(im) for im in opened])
+            out = remap_array(batch, k, in_mapping, output_mapping, sum_rc)
+            list(pool.map(lambda t: save(t[0], out[t[1]], opened[t[1]].info), [(md, i) for i, md in enumerate(mds)]))
+            written += len(mds)
+    return written

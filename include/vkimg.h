@@ -80,6 +80,21 @@ int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
                     const uint64_t* lengths, uint32_t nsamples, int k,
                     uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status);
 
+/* vk_count_device restricted to a pseudo-random subset of each sample's reads: stands where the
+ * reference runs `reformat.sh samplebasestarget=N sampleseed=S` once per output size before dsk
+ * (split_fastq / run_parallel_reformats, commands/image.py:577-725).  Not bit-compatible with
+ * BBTools' sampler (statistical equivalent, opt-in): read r of sample i is counted iff
+ * hash32(seeds[i], offset of the newline ending r's header line) < thresholds[i], thresholds in
+ * [0, 2^32] (2^32 = every read) -- a pure function of the file's bytes, independent of how the
+ * library splits the sample.  seeds/thresholds are host arrays.  d_sites[nsamples][2] (device,
+ * may be NULL) receives the bytes of all sequence lines (the reference's `nsites`, :669-675) and
+ * of the sequence lines of the reads taken. */
+int vk_count_sampled_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
+                            const uint64_t* lengths, uint32_t nsamples, int k,
+                            uint32_t parts_per_sample, const uint64_t* seeds,
+                            const uint64_t* thresholds, uint32_t* d_hist, uint32_t* d_status,
+                            uint64_t* d_sites);
+
 /* Replaces make_image()'s arithmetic = `dsk2ascii` dump + join/groupby +
  * count+1 scatter + 256-quantile rank binning (commands/image.py:864-919) for a
  * batch of histograms.  d_img[nsamples][npix] receives the uint8 pixels. */

@@ -56,6 +56,21 @@ def count_fastq(data, k):
     return fwd, nwin.value, st
 
 
+def count_fastq_sampled(data, k, seed, threshold):
+    """count_fastq over the reads taken by the subsampling rule; returns (fwd, nwindows, status,
+    (sites_all, sites_taken))."""
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    fwd = np.zeros(4 ** k, dtype=np.uint32)
+    nwin = C.c_uint64(0)
+    sites = (C.c_uint64 * 2)()
+    L = lib()
+    L.vko_count_fastq_sampled.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64,
+                                          C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    st = L.vko_count_fastq_sampled(buf.ctypes.data if buf.size else None, buf.size, k, seed, threshold,
+                                   _p(fwd, C.c_uint32), C.byref(nwin), sites)
+    return fwd, nwin.value, st, (sites[0], sites[1])
+
+
 def strand_merge(fwd, k):
     fwd = np.ascontiguousarray(fwd, dtype=np.uint32)
     tot = np.empty_like(fwd)

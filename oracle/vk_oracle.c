@@ -99,6 +99,61 @@ int vko_count_fastq(const uint8_t* buf, size_t n, int k, uint32_t* fwd, uint64_t
     return status;
 }
 
+/* Read subsampling (the build's stand-in for `reformat.sh samplebasestarget`, which the reference
+ * runs before dsk, commands/image.py:577-630; BBTools' sampler itself is not reproducible here, so
+ * this is the build's own rule, restated independently of the kernels): a read is taken iff
+ * hash32(seed, offset of the newline that ends its header line) < threshold, threshold in [0, 2^32]. */
+static uint32_t vko_sample_hash(uint64_t seed, uint64_t anchor) {
+    uint32_t h = (uint32_t)anchor ^ (uint32_t)seed;
+    h += (uint32_t)(anchor >> 32) * 0x9E3779B1u + (uint32_t)(seed >> 32);
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+/* vko_count_fastq over the taken reads only.  sites[0] = bytes of all sequence lines (the
+ * reference's nsites, image.py:669-675: len(line) - 1), sites[1] = of the taken reads' lines. */
+int vko_count_fastq_sampled(const uint8_t* buf, size_t n, int k, uint64_t seed, uint64_t threshold,
+                            uint32_t* fwd, uint64_t* nwin, uint64_t* sites) {
+    if (k < 1 || k > 15 || !fwd || threshold > (1ull << 32)) return VKO_EINVAL;
+    const uint32_t mask = (1u << (2 * k)) - 1u;
+    uint64_t windows = 0, all = 0, taken = 0;
+    size_t pos = 0;
+    unsigned line = 0;
+    int status = VKO_OK, take = 0;
+    while (pos < n) {
+        size_t e = pos;
+        while (e < n && buf[e] != '\n') e++;
+        unsigned ph = line & 3u;
+        if (ph == 0) {
+            if (buf[pos] != '@') status = VKO_EFORMAT;
+            take = (e < n) && ((uint64_t)vko_sample_hash(seed, (uint64_t)e) < threshold);
+        } else if (ph == 2) {
+            if (e == pos || buf[pos] != '+') status = VKO_EFORMAT;
+        } else if (ph == 1) {
+            all += e - pos;
+            if (take) {
+                taken += e - pos;
+                uint32_t fw = 0;
+                int run = 0;
+                for (size_t i = pos; i < e; i++) {
+                    int c = base_code(buf[i]);
+                    if (c < 0) { run = 0; continue; }
+                    fw = ((fw << 2) | (uint32_t)c) & mask;
+                    if (++run >= k) { fwd[fw]++; windows++; }
+                }
+            }
+        }
+        line++;
+        pos = e + 1;
+    }
+    if (n > 0 && (line & 3u) != 0) status = VKO_EFORMAT;
+    if (nwin) *nwin = windows;
+    if (sites) { sites[0] = all; sites[1] = taken; }
+    return status;
+}
+
 /* Strand merge: tot[c] = number of windows whose canonical class is {c, rc(c)}.
  * This is what reaches a pixel after image.py:900-903 whichever spelling dsk
  * printed.  Palindromes (even k) are counted once. */

@@ -51,8 +51,22 @@ uint32_t sync_phase(const uint8_t* s, uint64_t w0, uint64_t len) {
     return cnt & 3u;
 }
 
+// wave_stream's SUB branch needs the newline before the pre-block when a range is entered inside a
+// sequence line (last_newline_before in vkimg.hip)
+static uint64_t last_newline_before(const uint8_t* s, uint64_t end) {
+    while (end > 0)
+        if (s[--end] == '\n') return end;
+    return ~0ull;
+}
+
+struct Sub {
+    bool on;
+    uint64_t seed, threshold;
+    uint64_t sites[2];
+};
+
 template <int K>
-int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status) {
+int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status, Sub* sub = nullptr) {
     const uint32_t ncode = 1u << (2 * K);
     std::vector<uint32_t> raw(ncode, 0u);
     const uint64_t nblk = (len + 63) >> 6;
@@ -80,7 +94,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
             if (ph0 != prev_end) st |= 2u;
             const long long o0 = (long long)w0 - 64;
             const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
-            uint32_t carry_c = 0, carry_bad = 0x55555555u, pph = 0;
+            uint32_t carry_c = 0, carry_bad = 0x55555555u, pph = 0, sub_carry = 0;
             for (uint64_t it = 0; it < npieces; ++it) {
                 uint8_t piece[kPiece];
                 for (int i = 0; i < kPiece; ++i) {
@@ -105,11 +119,16 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                 bool any_gt3 = false;
                 for (int lane = 0; lane < 64; ++lane) any_gt3 |= c[lane] > 3;
                 uint32_t excl = 0;
+                if (sub && sub->on && it == 0 && w0 != 0 && (pph & 3u) == 1u) {
+                    const uint64_t a = last_newline_before(s, (uint64_t)o0);
+                    sub_carry = (a != ~0ull && vkl::sample_take(sub->seed, a, sub->threshold)) ? 1u : 0u;
+                }
                 for (int lane = 0; lane < 64; ++lane) {
                     const uint32_t lph = (pph + excl) & 3u;
                     excl += c[lane];
+                    uint32_t s_raw = 0;
                     vkl::Mask128 seq = any_gt3 ? vkl::seq_mask_general(lb[lane].NL, lph)
-                                               : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below);
+                                               : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
                     uint32_t bad[4], ok[4];
                     vkl::bad_mask(lb[lane], seq, bad);
                     const uint32_t badh = carry_bad, ch = carry_c;  // lane-1's (or last piece's lane 63)
@@ -117,6 +136,31 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     carry_c = lb[lane].C[3];
                     vkl::ok_mask<K>(badh, bad, ok);
                     if (it == 0 && lane == 0) ok[0] = ok[1] = ok[2] = ok[3] = 0;
+                    if (sub && sub->on) {
+                        // lanes run in order here, so the max-scan of the kernel is a running value
+                        const uint64_t base = (uint64_t)(o0 + (long long)it * kPiece) + 64ull * lane;
+                        uint32_t first[4], inc[4], anchors, take;
+                        if (any_gt3) {
+                            anchors = vkl::sample_strings_general(lb[lane].NL, lph, base, sub->seed, sub->threshold,
+                                                                  first, inc, take);
+                        } else {
+                            anchors = (lph != 1u && s_raw <= 64u) ? 1u : 0u;
+                            take = (anchors && vkl::sample_take(sub->seed, base + s_raw - 1u, sub->threshold)) ? 1u : 0u;
+                            for (int g = 0; g < 4; ++g) { first[g] = anchors ? 0u : ~0u; inc[g] = take ? ~0u : 0u; }
+                        }
+                        const uint32_t inh = 0u - sub_carry;
+                        if (anchors) sub_carry = take;
+                        const bool mine = !(it == 0 && lane == 0) && base < w1;
+                        for (int g = 0; g < 4; ++g) {
+                            const uint32_t takem = (first[g] & inh) | inc[g];
+                            ok[g] &= takem;
+                            if (mine) {
+                                const uint32_t sites = seq.w[g] & ~lb[lane].NL[g] & 0x55555555u;
+                                sub->sites[0] += vkl::popc(sites);
+                                sub->sites[1] += vkl::popc(sites & takem);
+                            }
+                        }
+                    }
                     vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; }, [] {});
                 }
                 pph += total;
@@ -143,4 +187,21 @@ extern "C" int emul_count(const uint8_t* s, uint64_t len, int k, uint32_t parts,
         case 9: return count_impl<9>(s, len, parts, hist, status);
         default: return 1;
     }
+}
+
+extern "C" int emul_count_sampled(const uint8_t* s, uint64_t len, int k, uint32_t parts, uint64_t seed,
+                                  uint64_t threshold, uint32_t* hist, uint32_t* status, uint64_t* sites) {
+    Sub sub = {true, seed, threshold, {0, 0}};
+    int rc;
+    switch (k) {
+        case 5: rc = count_impl<5>(s, len, parts, hist, status, &sub); break;
+        case 6: rc = count_impl<6>(s, len, parts, hist, status, &sub); break;
+        case 7: rc = count_impl<7>(s, len, parts, hist, status, &sub); break;
+        case 8: rc = count_impl<8>(s, len, parts, hist, status, &sub); break;
+        case 9: rc = count_impl<9>(s, len, parts, hist, status, &sub); break;
+        default: return 1;
+    }
+    sites[0] = sub.sites[0];
+    sites[1] = sub.sites[1];
+    return rc;
 }

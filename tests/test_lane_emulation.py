@@ -34,6 +34,20 @@ def emul():
         st = C.c_uint32(0)
         assert L.emul_count(pad.ctypes.data, buf.size, k, parts, hist.ctypes.data, C.byref(st)) == 0
         return hist, st.value
+
+    def run_sampled(fq, k, parts, seed, threshold):
+        buf = np.frombuffer(bytes(fq), dtype=np.uint8) if not isinstance(fq, np.ndarray) else fq
+        pad = np.zeros(buf.size + 64, dtype=np.uint8)
+        pad[:buf.size] = buf
+        hist = np.zeros(4 ** k, dtype=np.uint32)
+        st = C.c_uint32(0)
+        sites = (C.c_uint64 * 2)()
+        L.emul_count_sampled.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.emul_count_sampled(pad.ctypes.data, buf.size, k, parts, seed, threshold, hist.ctypes.data,
+                                    C.byref(st), sites) == 0
+        return hist, st.value, (sites[0], sites[1])
+    run.sampled = run_sampled
     return run
 
 
@@ -80,3 +94,24 @@ def test_emulated_wave_fuzz(emul):
         got, status = emul(fq, k, parts)
         assert status == 0, trial
         assert np.array_equal(got, want), (trial, k, parts, len(fq))
+
+
+def test_emulated_read_subsampling_equals_oracle(emul):
+    """The kernels' per-block sampling rule (anchor detection, inheritance across blocks, pieces and
+    byte ranges, the position-by-position path for short lines) == the oracle's per-read rule."""
+    from fastq_cases import random_fastq, rec
+    rng = np.random.default_rng(77)
+    blobs = [random_fastq(rng) for _ in range(40)]
+    blobs.append(synth.sample_fastq(5, 3000, 150, dist=1).tobytes())
+    blobs.append(b"".join(rec(f"r{i}", "ACGTAC") for i in range(3000)))          # > 3 newlines per block
+    blobs.append(b"".join(rec(f"q{i}", "ACGT" * 700) for i in range(12)))        # lines longer than a piece
+    for j, fq in enumerate(blobs):
+        k = 5 + j % 5
+        seed = 1000 + j
+        for thr in (1 << 31, (1 << 32) // 10, 1 << 32, 0):
+            want, nwin, st, wsites = oracle.count_fastq_sampled(fq, k, seed, thr)
+            assert st == 0
+            for parts in (1, 3):
+                got, status, sites = emul.sampled(fq, k, parts, seed, thr)
+                assert status == 0 and sites == wsites, (j, thr, parts, sites, wsites)
+                assert np.array_equal(got, want), (j, thr, parts)

@@ -1,0 +1,171 @@
+"""Read subsampling on the GPU: the ladder arithmetic of split_fastq
+(commands/image.py:677-713, pinned by golden `split_cases` captured from the reference), and the
+sampled count kernel against the oracle's restatement of the same rule."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fastq_cases
+from oracle import oracle
+from varkoder_amd import subsample, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def manifest():
+    with open(os.path.join(ROOT, "tests", "golden", "manifest.json")) as f:
+        return json.load(f)
+
+
+def test_ladder_and_names_match_split_fastq(manifest):
+    for case in manifest["split_cases"]:
+        kw = dict(min_bp=case["min_bp"], max_bp=case["max_bp"], is_query=case["is_query"])
+        if "raises" in case:
+            with pytest.raises(Exception, match="less than minimum data"):
+                subsample.sites_ladder(case["nsites"], **kw)
+            continue
+        sizes = subsample.sites_ladder(case["nsites"], **kw)
+        assert sizes == case["sites_per_file"], case
+        assert [subsample.split_name(case["prefix"], bp) + ".fq.gz" for bp in sizes] == case["outfiles"]
+        assert [int(case["seed"]) + i for i in range(len(sizes))] == case["sampleseeds"]
+
+
+def test_threshold_is_a_probability():
+    assert subsample.threshold(10, 10) == 1 << 32 and subsample.threshold(11, 10) == 1 << 32
+    assert subsample.threshold(0, 10) == 0
+    assert subsample.threshold(5_000_000, 20_000_000) == 1 << 30
+    assert subsample.threshold(1, 0) == 1 << 32
+
+
+def test_oracle_rule_on_a_hand_case():
+    # two reads; thresholds 0 and 2^32 take none / all
+    data = fastq_cases.rec("a", "ACGTACGTAC") + fastq_cases.rec("b", "GGGGGGGGCC")
+    full = oracle.count_fastq(data, 5)
+    none = oracle.count_fastq_sampled(data, 5, 7, 0)
+    allr = oracle.count_fastq_sampled(data, 5, 7, 1 << 32)
+    assert none[1] == 0 and none[3] == (20, 0)
+    assert allr[1] == full[1] and np.array_equal(allr[0], full[0]) and allr[3] == (20, 20)
+    # some seed separates the two reads (each read is all-or-nothing)
+    seen = set()
+    for seed in range(64):
+        fwd, nwin, st, sites = oracle.count_fastq_sampled(data, 5, seed, 1 << 31)
+        assert st == 0 and nwin in (0, 6, 12) and sites[1] in (0, 10, 20)
+        seen.add(sites[1])
+    assert seen == {0, 10, 20}
+
+
+def _engine(k):
+    from varkoder_amd.engine import ImageEngine
+    return ImageEngine(k=k, mapping="cgr")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [5, 7, 8])
+def test_sampled_count_matches_the_oracle(k):
+    eng = _engine(k)
+    cases = fastq_cases.edge_cases()
+    names = ["one_read", "n_in_middle", "lowercase", "crlf", "no_final_newline", "qual_starts_at_plus", "poly_a"]
+    blobs = [cases[n] for n in names]
+    blobs += [fastq_cases.random_fastq(np.random.default_rng(s), 400) for s in range(3)]
+    blobs.append(synth.sample_fastq(3, 4000, 150, dist=1).tobytes())          # 1.28 MB: several waves
+    blobs.append(b"".join(fastq_cases.rec(f"r{i}", "ACGTTGCA" * 2) for i in range(3000)))   # short reads
+    blobs.append(b"".join(fastq_cases.rec(f"r{i}", "ACGTAC") for i in range(5000)))         # > 3 newlines per block
+    fq, offs, lens = eng.upload(blobs)
+    for seed, frac in ((1, 0.5), (2, 0.1), (99, 0.9), (5, 1.0), (6, 0.0)):
+        thr = min(1 << 32, int(frac * (1 << 32)))
+        for parts in (0, 1, 5):
+            hist, status, sites = eng.count_sampled(fq, offs, lens, seed, thr, parts=parts)
+            h = hist.cpu().numpy().view(np.uint32)
+            st = status.cpu().numpy()
+            si = sites.cpu().numpy()
+            for i, blob in enumerate(blobs):
+                want, nwin, wst, wsites = oracle.count_fastq_sampled(blob, k, seed, thr)
+                assert st[i] == 0 and wst == 0, (i, seed, parts)
+                assert tuple(int(x) for x in si[i]) == wsites, (i, seed, frac, parts)
+                assert np.array_equal(h[i], want), (i, seed, frac, parts)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_sampling_fraction_and_seed_independence():
+    eng = _engine(7)
+    blob = synth.sample_fastq(11, 40000, 150, dist=0).tobytes()
+    fq, offs, lens = eng.upload([blob])
+    fracs = []
+    hists = []
+    for seed in (10, 11):
+        hist, status, sites = eng.count_sampled(fq, offs, lens, seed, 1 << 30)      # p = 1/4
+        s = sites.cpu().numpy()[0]
+        assert s[0] == 40000 * 150
+        fracs.append(s[1] / s[0])
+        hists.append(hist.cpu().numpy().copy())
+    assert all(abs(f - 0.25) < 0.01 for f in fracs), fracs          # 40000 reads: sd 0.0022
+    assert not np.array_equal(hists[0], hists[1])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_ladder_counts_on_device():
+    eng = _engine(7)
+    blobs = [synth.sample_fastq(s, 20000, 150, dist=1).tobytes() for s in (0, 1)]      # 3 Mbp each
+    blobs.append(synth.sample_fastq(2, 200, 150).tobytes())                            # 30 kbp: too little
+    fq, offs, lens = eng.upload(blobs)
+    recs = subsample.ladder_counts(eng, fq, offs, lens, seed=100, min_bp=500_000, max_bp=2_000_000)
+    assert [r["nsites"] for r in recs] == [3_000_000, 3_000_000, 30_000]
+    assert recs[2]["error"] and not recs[2]["steps"]
+    for i in (0, 1):
+        assert [bp for bp, _, _ in recs[i]["steps"]] == [2_000_000, 1_000_000, 500_000]
+        for level, (bp, hist, taken) in enumerate(recs[i]["steps"]):
+            thr = subsample.threshold(bp, 3_000_000)
+            want, nwin, st, sites = oracle.count_fastq_sampled(blobs[i], 7, 100 + level, thr)
+            assert np.array_equal(hist.cpu().numpy().view(np.uint32), want)
+            assert taken == sites[1] and abs(taken - bp) < 0.05 * bp
+    # no max_bp: the first step is the whole file, counted once
+    recs = subsample.ladder_counts(eng, fq, offs[:1], lens[:1], seed=3, min_bp=1_000_000, max_bp=None)
+    assert [bp for bp, _, _ in recs[0]["steps"]] == [3_000_000, 2_000_000, 1_000_000]
+    assert np.array_equal(recs[0]["steps"][0][1].cpu().numpy().view(np.uint32), oracle.count_fastq(blobs[0], 7)[0])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_cli_from_clean_writes_the_ladder(tmp_path):
+    """`image --from-clean`: steps C+D+E from cleaned reads; every PNG equals the oracle's image of
+    the oracle's sampled counts for the seed / threshold the command derives."""
+    import gzip
+
+    import pandas as pd
+    from PIL import Image
+    from varkoder_amd import cli
+    clean = tmp_path / "int" / "clean_reads"
+    clean.mkdir(parents=True)
+    blobs = {"sampA": synth.sample_fastq(4, 20000, 150, dist=1).tobytes(),
+             "sampB": synth.sample_fastq(5, 8000, 150).tobytes()}
+    (clean / "sampA.fq").write_bytes(blobs["sampA"])
+    with gzip.open(clean / "sampB.fq.gz", "wb") as f:
+        f.write(blobs["sampB"])
+    out, stats = tmp_path / "images", tmp_path / "stats.csv"
+    cli.main(["image", "--from-clean", "-k", "7", "-p", "cgr", "-m", "500K", "-M", "2M", "-R", "5", "-o", str(out),
+              "-f", str(stats), str(tmp_path / "int")])
+    ladders = {"sampA": [2_000_000, 1_000_000, 500_000], "sampB": [1_200_000, 1_000_000, 500_000]}
+    rng = np.random.default_rng(5)
+    pix = oracle.cgr_lut(7)
+    got = sorted(p.name for p in out.glob("*.png"))
+    want_names = sorted(f"{s}@{bp // 1000:08d}K+cgr+k7.png" for s, l in ladders.items() for bp in l)
+    assert got == want_names
+    for i, s in enumerate(sorted(blobs)):
+        seed = int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63)
+        nsites = 150 * (20000 if s == "sampA" else 8000)
+        for level, bp in enumerate(ladders[s]):
+            thr = subsample.threshold(bp, nsites)
+            fwd = oracle.count_fastq_sampled(blobs[s], 7, seed + level, thr)[0]
+            img = oracle.image(oracle.strand_merge(fwd, 7), 7, pix, 4 ** 7).reshape(128, 128)
+            im = Image.open(out / f"{s}@{bp // 1000:08d}K+cgr+k7.png")
+            assert np.array_equal(np.array(im), img), (s, bp)
+            assert im.info["varkoderMapping"] == "cgr"
+    df = pd.read_csv(stats)
+    assert list(df["sample"]) == ["sampA", "sampB"]
+    assert list(df["splitting_bp_per_file"]) == ["2000000,1000000,500000", "1200000,1000000,500000"]
+    assert {"7mer_counting_time", "k7_img_time", "splitting_time"} <= set(df.columns)

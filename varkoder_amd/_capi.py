@@ -13,7 +13,7 @@ VK_ST_BAD_START, VK_ST_BAD_PHASE = 1, 2
 SYMBOLS = ("vk_abi_version", "vk_strerror", "vk_last_hip_error", "vk_ctx_create", "vk_ctx_destroy",
            "vk_ctx_sync", "vk_set_mapping", "vk_count_device", "vk_image_device",
            "vk_fastq_to_image_device", "vk_count_host", "vk_image_host", "vk_synth_fastq_device", "vk_remap_host", "vk_preprocess_device",
-           "vk_last_count_launch")
+           "vk_last_count_launch", "vk_count_sampled_device")
 
 _lib = None
 
@@ -44,6 +44,7 @@ def lib():
     L.vk_ctx_sync.argtypes = [vp]
     L.vk_set_mapping.argtypes = [vp, C.c_int, u32p, C.c_uint32]
     L.vk_count_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_int, C.c_uint32, vp, vp]
+    L.vk_count_sampled_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_int, C.c_uint32, u64p, u64p, vp, vp, vp]
     L.vk_image_device.argtypes = [vp, vp, C.c_uint32, C.c_int, vp]
     L.vk_fastq_to_image_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_int, C.c_uint32, vp, vp, vp]
     L.vk_count_host.argtypes = [vp, vp, C.c_size_t, C.c_int, u32p, u32p]

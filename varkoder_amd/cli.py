@@ -49,6 +49,10 @@ def setup_parser():
     p.add_argument("-X", "--no-image", action="store_true", help="nothing to do here without images")
     p.add_argument("-T", "--trim-bp", default="10,10", help="upstream (fastp) option; accepted for parity")
     p.add_argument("--labels-csv", help="optional CSV `sample,labels` (labels separated by ';')")
+    p.add_argument("--from-clean", action="store_true",
+                   help="input holds cleaned but UNSPLIT reads (`<int>/clean_reads/<sample>.fq.gz`): draw the "
+                        "1-2-5 ladder of subsamples between --min-bp and --max-bp on the GPU (stands in for "
+                        "reformat.sh; statistically equivalent, not the same random reads)")
     c = sub.add_parser("convert", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                        help="Convert images between different kmer mappings.")          # cli.py:447-482
     c.add_argument("-R", "--seed", type=int, help="accepted for parity")
@@ -84,6 +88,49 @@ def read_labels(path):
     return {r["sample"]: [x for x in r["labels"].split(LABELS_SEP) if x] for _, r in df.iterrows()}
 
 
+def parse_size(text):
+    """humanfriendly.parse_size for the forms the reference's flags take ("500K", "200M", "0"):
+    decimal multiples, optional trailing B (commands/image.py:1013)."""
+    t = str(text).strip().upper().removesuffix("B")
+    mult = {"K": 10 ** 3, "M": 10 ** 6, "G": 10 ** 9, "T": 10 ** 12}
+    if t and t[-1] in mult:
+        return int(float(t[:-1]) * mult[t[-1]])
+    return int(float(t))
+
+
+def run_image_from_clean(args, outdir, rank, world, local_rank):
+    import numpy as np
+    import pandas as pd
+    from .pipeline import clean_to_images
+    from .shard import gather_stats
+    src = Path(args.input)
+    if (src / "clean_reads").is_dir():
+        src = src / "clean_reads"
+    files = sorted(f for f in src.iterdir() if f.is_file() and f.name.endswith((".fq", ".fq.gz", ".fastq", ".fastq.gz")))
+    if not files:
+        raise Exception("No files found in input. Please check.")
+    samples = [str(f.name.removesuffix("".join(f.suffixes))) for f in files]
+    max_bp = None if str(args.max_bp) == "0" else parse_size(args.max_bp)     # cli.py:496-501
+    rng = np.random.default_rng(args.seed)
+    # image.py:1017: str(row index) + str(random integer), one draw per sample in row order
+    seeds = {s: int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63) for i, s in enumerate(samples)}
+    labels = read_labels(args.labels_csv)
+    eprint("Subsampling, counting kmers and creating images for", len(files), "samples")
+    per_sample = clean_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping,
+                                 min_bp=parse_size(args.min_bp), max_bp=max_bp, seeds=seeds, labels=labels,
+                                 device=local_rank, rank=rank, world=world, io_threads=max(1, args.n_threads) * 4,
+                                 verbose=args.verbose)
+    merged = gather_stats(per_sample)
+    if rank == 0:
+        rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
+        pd.DataFrame(rows).to_csv(args.stats_file, index=False)
+        eprint("All images done, saved in", str(outdir))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def run_image(args):
     import pandas as pd
     from .pipeline import fastqs_to_images
@@ -103,6 +150,8 @@ def run_image(args):
         outdir.mkdir(parents=True)
     if world > 1:
         dist.barrier()
+    if args.from_clean:
+        return run_image_from_clean(args, outdir, rank, world, local_rank)
     src = Path(args.input)
     if (src / "split_fastqs").is_dir():
         src = src / "split_fastqs"

@@ -195,8 +195,11 @@ VKL_FN uint32_t first_newline(const uint32_t nl[4]) {
 // one stretch of sequence per 64 bytes).  lph = line phase at the block start
 // (0 header, 1 sequence, 2 plus, 3 quality).  below(q) = ones_below(q), above(q) = ~below(q);
 // the kernel serves both from LDS tables (one ds_read_b128 each).
+// s_raw receives the unclamped start of the interval: 0 when the block begins inside a sequence
+// line, p+1 (1..64) when the newline at position p -- the end of a header line -- opens one here,
+// more than 64 when no sequence line starts in this block.
 template <typename Below, typename Above>
-VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Above above) {
+VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Above above, uint32_t& s_raw) {
     const uint32_t d = (1u - lph) & 3u;  // newlines to skip before a sequence line starts
     const uint32_t p1 = first_newline(NL);
     Mask128 m = above(umin(p1 + 1u, 64u));
@@ -211,10 +214,63 @@ VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Ab
     const uint32_t pr = alignbit(64u, lo, 8u * d);
     const uint32_t s = ((pr & 0xFFu) + 1u) & 0xFFu;
     const uint32_t e = (pr >> 8) & 0xFFu;
+    s_raw = s;
     const Mask128 ms = above(umin(s, 64u)), me = below(umin(e, 64u));
     Mask128 out;
     for (int g = 0; g < 4; ++g) out.w[g] = me.w[g] & ms.w[g];
     return out;
+}
+
+template <typename Below, typename Above>
+VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Above above) {
+    uint32_t s_raw;
+    return seq_mask_fast(NL, lph, below, above, s_raw);
+}
+
+// ---- read subsampling (vk_count_sampled_device) ------------------------------------------------
+// A read is identified by the sample offset of its ANCHOR, the newline that ends its header line,
+// and is counted iff sample_hash(seed, anchor) < threshold (threshold in [0, 2^32]): a pure function
+// of the file's bytes, so every split of a sample into byte ranges selects the same reads.
+VKL_FN uint32_t sample_hash(uint64_t seed, uint64_t anchor) {
+    uint32_t h = static_cast<uint32_t>(anchor) ^ static_cast<uint32_t>(seed);
+    h += static_cast<uint32_t>(anchor >> 32) * 0x9E3779B1u + static_cast<uint32_t>(seed >> 32);
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+VKL_FN bool sample_take(uint64_t seed, uint64_t anchor, uint64_t threshold) {
+    return static_cast<uint64_t>(sample_hash(seed, anchor)) < threshold;
+}
+
+// Inclusion strings of one 64-byte block that starts at sample offset `base` in line phase lph, for
+// any number of newlines: `first` = positions up to and including the first anchor (or all 64 when
+// the block has none) -- they belong to the read the block was entered in; `inc` = positions after
+// an anchor whose read is taken.  Returns anchors seen; last_take = decision of the last one.
+VKL_FN uint32_t sample_strings_general(const uint32_t NL[4], uint32_t lph, uint64_t base, uint64_t seed,
+                                       uint64_t threshold, uint32_t first[4], uint32_t inc[4], uint32_t& last_take) {
+    uint32_t cur = lph & 3u, anchors = 0, take = 0;
+    last_take = 0;
+    for (int g = 0; g < 4; ++g) {
+        uint32_t f = 0, n = 0;
+        const uint32_t nl = NL[g];
+        for (uint32_t b = 0; b < 32; b += 2) {
+            if (anchors == 0) f |= 3u << b;
+            else if (take) n |= 3u << b;
+            if ((nl >> b) & 1u) {
+                if (cur == 0u) {
+                    ++anchors;
+                    take = sample_take(seed, base + 16u * static_cast<uint32_t>(g) + (b >> 1), threshold) ? 1u : 0u;
+                    last_take = take;
+                }
+                cur = (cur + 1u) & 3u;
+            }
+        }
+        first[g] = f;
+        inc[g] = n;
+    }
+    return anchors;
 }
 
 VKL_FN Mask128 ones_not_below(uint32_t q) {

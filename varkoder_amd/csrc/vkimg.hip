@@ -279,6 +279,51 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
     }
 }
 
+// ---- read subsampling (vk_count_sampled_device; vk_lane.h: sample_hash) ------------------------
+struct SubParams {
+    const uint64_t* seeds;        // [nsamples]
+    const uint64_t* thresholds;   // [nsamples], in [0, 2^32]
+    unsigned long long* sites;    // [nsamples][2]: bytes of sequence lines, of which in taken reads; may be null
+};
+
+struct SubWave {                  // per-wave state of a subsampling launch
+    uint64_t seed, threshold;
+    uint32_t sites, sites_taken;  // per-lane partial sums
+};
+
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t x) {
+    x = max(x, dpp_or_zero<0x111, 0xF>(x));
+    x = max(x, dpp_or_zero<0x112, 0xF>(x));
+    x = max(x, dpp_or_zero<0x114, 0xF>(x));
+    x = max(x, dpp_or_zero<0x118, 0xF>(x));
+    x = max(x, dpp_or_zero<0x142, 0xA>(x));
+    x = max(x, dpp_or_zero<0x143, 0xC>(x));
+    return x;
+}
+
+// Offset of the last newline before sample offset `end` (end > 0), or ~0 when there is none.
+// Wave-uniform; walks back 1 KiB at a time (one step for ordinary read lengths).
+__device__ uint64_t last_newline_before(const uint8_t* sbase, uint64_t end, int lane) {
+    while (end > 0) {
+        const long long off = static_cast<long long>(end) - 1024 + 16ll * lane;
+        const uint4 v = load_granule_s(sbase, off, end);
+        const uint32_t f[4] = {nl_flags(v.x), nl_flags(v.y), nl_flags(v.z), nl_flags(v.w)};
+        const bool any = off >= 0 && (f[0] | f[1] | f[2] | f[3]) != 0u;
+        const unsigned long long b = __ballot(any);
+        if (b) {
+            const int hl = 63 - __clzll(b);
+            uint32_t pos = 0;  // byte of the last newline inside the granule
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (f[d]) pos = 4u * d + ((31u - __clz(f[d])) >> 3);
+            const uint32_t p = lane_bcast(pos, hl);
+            return end - 1024 + 16ull * hl + p;
+        }
+        end = end > 1024 ? end - 1024 : 0;
+    }
+    return ~0ull;
+}
+
 #ifdef VK_STAMPS
 // Diagnostic build only (tools/stamps.sh): per-segment cycle sums of the piece loop, written to a
 // debug buffer that nothing else reads.  Never quote this build's run time.
@@ -295,10 +340,11 @@ __device__ unsigned long long g_vk_stamps[8];
     } while (0)
 #endif
 
-template <int K, typename Windows>
+template <int K, bool SUB, typename Windows>
 __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
                                             uint64_t w1, uint4* st, const uint4* below, const uint4* above,
-                                            int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end) {
+                                            int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end,
+                                            SubWave& sw) {
     const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(st), lane) : 0u;
     ph_start = ph0;
 
@@ -329,6 +375,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
     load_piece(0);
     uint32_t carry_c = 0u, carry_bad = 0x55555555u;
     uint32_t pph = 0;  // line phase at the start of the current piece
+    uint32_t sub_carry = 0u;  // SUB: is the read that runs into the current piece taken?
     auto tbl_below = [&](uint32_t q) {
         uint4 v = below[q];
         vkl::Mask128 m;
@@ -370,8 +417,10 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         const uint32_t lph = (pph + incl - c) & 3u;
 
         vkl::Mask128 seq;
-        if (__any(c > 3u)) seq = vkl::seq_mask_general(lb.NL, lph);
-        else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above);
+        const bool degenerate = __any(c > 3u);
+        uint32_t s_raw = 0;
+        if (degenerate) seq = vkl::seq_mask_general(lb.NL, lph);
+        else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above, s_raw);
         uint32_t bad[4], ok[4];
         vkl::bad_mask(lb, seq, bad);
 
@@ -382,6 +431,46 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
 
         vkl::ok_mask<K>(badh, bad, ok);
         if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+
+        if constexpr (SUB) {
+            // Which read does each position belong to, and is that read taken?  A block either has
+            // an anchor (the newline that ends a header line) and decides for what follows it, or
+            // inherits the decision of the nearest anchor before it: a max-scan over
+            // (lane + 1) << 1 | take, seeded with the decision carried in from the previous piece.
+            const uint64_t base = static_cast<uint64_t>(o0 + static_cast<long long>(it) * kPiece) + 64ull * lane;
+            if (it == 0 && w0 != 0 && (pph & 3u) == 1u) {
+                // the range is entered inside a sequence line whose header ended before the pre-block
+                const uint64_t a = last_newline_before(sbase, static_cast<uint64_t>(o0), lane);
+                sub_carry = (a != ~0ull && vkl::sample_take(sw.seed, a, sw.threshold)) ? 1u : 0u;
+            }
+            uint32_t first[4], inc[4], anchors, take;
+            if (degenerate) {
+                anchors = vkl::sample_strings_general(lb.NL, lph, base, sw.seed, sw.threshold, first, inc, take);
+            } else {
+                anchors = (lph != 1u && s_raw <= 64u) ? 1u : 0u;
+                take = (anchors && vkl::sample_take(sw.seed, base + s_raw - 1u, sw.threshold)) ? 1u : 0u;
+                const uint32_t f = anchors ? 0u : 0xFFFFFFFFu, n = take ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { first[g] = f; inc[g] = n; }
+            }
+            const uint32_t v = anchors ? (((static_cast<uint32_t>(lane) + 1u) << 1) | take) : 0u;
+            const uint32_t scan = wave_inclusive_max(v);
+            const uint32_t inherited = max(wave_prev_lane(scan, 0u), sub_carry) & 1u;
+            sub_carry = max(lane_bcast(scan, 63), sub_carry) & 1u;
+            const uint32_t inh = 0u - inherited;
+            // the pre-block belongs to the previous range; bytes at or beyond w1 are zero fill
+            const bool mine = !(it == 0 && lane == 0) && base < w1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t takem = (first[g] & inh) | inc[g];
+                ok[g] &= takem;
+                if (mine) {  // (the position-by-position mask marks a line's own newline too)
+                    const uint32_t sites = seq.w[g] & ~lb.NL[g] & 0x55555555u;
+                    sw.sites += __popc(sites);
+                    sw.sites_taken += __popc(sites & takem);
+                }
+            }
+        }
         VK_STAMP(t3);
         windows(ch, lb.C, ok);  // the consumer's window stage (LDS histogram or bucket queues)
         pph += total;
@@ -408,11 +497,22 @@ __device__ __forceinline__ void fill_mask_tables(uint4* below, uint4* above, int
 }
 
 // K <= 7: the whole 4^K u32 histogram lives in LDS.
-template <int K>
+// Per-wave sums of a subsampling launch -> sites[sample][2].
+__device__ __forceinline__ void flush_sites(const SubParams& sp, uint32_t s, const SubWave& sw, int lane) {
+    if (!sp.sites) return;
+    const uint32_t a = lane_bcast(wave_inclusive_sum(sw.sites), 63);
+    const uint32_t b = lane_bcast(wave_inclusive_sum(sw.sites_taken), 63);
+    if (lane == 0) {
+        atomicAdd(&sp.sites[2ull * s], static_cast<unsigned long long>(a));
+        atomicAdd(&sp.sites[2ull * s + 1], static_cast<unsigned long long>(b));
+    }
+}
+
+template <int K, bool SUB>
 __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush, SubParams sp) {
     constexpr uint32_t NCODE = 1u << (2 * K);
     static_assert(NCODE <= kMaxBins, "LDS histogram too large");
 
@@ -444,8 +544,14 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
             windows_lds<K>(ch, C, ok, hist_base);
         };
-        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end);
+        SubWave sw = {0, 0, 0, 0};
+        if constexpr (SUB) {
+            sw.seed = sp.seeds[s];
+            sw.threshold = sp.thresholds[s];
+        }
+        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end, sw);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+        if constexpr (SUB) flush_sites(sp, s, sw, lane);
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 
@@ -486,11 +592,11 @@ __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane 
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
 }
 
-template <int K>
+template <int K, bool SUB>
 __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp) {
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp) {
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr uint32_t LB = 2 * K - 4;               // local bits of an entry
     constexpr uint32_t LMASK = (1u << LB) - 1u;
@@ -606,7 +712,13 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
             vkl::windows<K>(ch, C, ok, emit, after_group);
         };
-        wave_stream<K>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end);
+        SubWave sw = {0, 0, 0, 0};
+        if constexpr (SUB) {
+            sw.seed = sp.seeds[s];
+            sw.threshold = sp.thresholds[s];
+        }
+        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        if constexpr (SUB) flush_sites(sp, s, sw, lane);
         // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();
         uint32_t n = qcnt[wave][q];
@@ -1034,6 +1146,8 @@ struct vk_ctx {
     size_t spill_cap = 0;
     size_t spill_budget = 96ull << 30;  // bytes of HBM the spill path may use at a time
     // host-call staging
+    uint64_t* d_sub = nullptr;    // subsampling launches: seeds | thresholds
+    size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
     uint32_t* d_hist1 = nullptr;
@@ -1094,7 +1208,7 @@ uint32_t npad_of(uint32_t npix) {
 
 template <int K>
 int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
-                 uint32_t nsamples, uint32_t parts, uint64_t /*maxlen*/, uint32_t* d_hist) {
+                 uint32_t nsamples, uint32_t parts, uint64_t /*maxlen*/, uint32_t* d_hist, const SubParams* sub) {
     const uint32_t grid = nsamples * parts;
     const int atomic_flush = parts > 1 ? 1 : 0;
     if (atomic_flush)
@@ -1103,8 +1217,12 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     ctx->last_grid = grid;
     ctx->last_block = kCountThreads;
     ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * kPiece + 2 * 66 * 16;
-    hipLaunchKernelGGL((vk_count_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs,
-                       d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
+    if (sub)
+        hipLaunchKernelGGL((vk_count_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, *sub);
+    else
+        hipLaunchKernelGGL((vk_count_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
 }
@@ -1112,7 +1230,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
 // k = 8, 9: bucket pass + replay pass, in sub-batches that fit the spill budget.
 template <int K>
 int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
-                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist) {
+                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub) {
     constexpr uint32_t NCODE = 1u << (2 * K);
     // windows <= bytes/2; a uniform sample sends ~0.45*bytes/16 entries to each queue.  Room for
     // bytes/16 entries (2.2x) plus the run each wave may leave unfinished.
@@ -1143,9 +1261,19 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
         VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * kQueues * sizeof(uint32_t), ctx->stream));
         ctx->last_grid = n * parts;
-        hipLaunchKernelGGL((vk_bucket_kernel<K>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                           d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
-                           ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp);
+        if (sub) {
+            SubParams sp = *sub;  // this sub-batch's slice of the per-sample arrays
+            sp.seeds += s0;
+            sp.thresholds += s0;
+            if (sp.sites) sp.sites += 2ull * s0;
+            hipLaunchKernelGGL((vk_bucket_kernel<K, true>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                               d_fastq, d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
+                               ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, sp);
+        } else {
+            hipLaunchKernelGGL((vk_bucket_kernel<K, false>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                               d_fastq, d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
+                               ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, SubParams{});
+        }
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp,
                            d_hist + static_cast<size_t>(s0) * NCODE);
@@ -1210,7 +1338,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -1246,8 +1374,9 @@ int vk_set_mapping(vk_ctx* ctx, int k, const uint32_t* pix, uint32_t npix) {
     return VK_OK;
 }
 
-int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
-                    uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status) {
+static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                      uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status,
+                      const uint64_t* seeds, const uint64_t* thresholds, uint64_t* d_sites) {
     if (!ctx || !offsets || !lengths || !d_hist || !d_status || k < 5 || k > 9) return VK_EINVAL;
     if (nsamples == 0) return VK_OK;
     if (!d_fastq) return VK_EINVAL;
@@ -1272,18 +1401,49 @@ int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, c
     rc = upload_desc(ctx, offsets, lengths, nsamples);
     if (rc) return rc;
     const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
+    SubParams sp{};
+    const SubParams* sub = nullptr;
+    if (seeds) {
+        // seeds | thresholds travel like the descriptors (pageable source: the copy has read it on return)
+        rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_sub), &ctx->sub_cap, 2ull * nsamples * sizeof(uint64_t));
+        if (rc) return rc;
+        VK_HIP(ctx, hipMemcpyAsync(ctx->d_sub, seeds, nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(ctx->d_sub + nsamples, thresholds, nsamples * sizeof(uint64_t),
+                                   hipMemcpyHostToDevice, ctx->stream));
+        if (d_sites) VK_HIP(ctx, hipMemsetAsync(d_sites, 0, 2ull * nsamples * sizeof(uint64_t), ctx->stream));
+        sp.seeds = ctx->d_sub;
+        sp.thresholds = ctx->d_sub + nsamples;
+        sp.sites = reinterpret_cast<unsigned long long*>(d_sites);
+        sub = &sp;
+    }
     switch (k) {
-        case 5: rc = launch_count<5>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
-        case 6: rc = launch_count<6>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
-        case 7: rc = launch_count<7>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
-        case 8: rc = launch_spill<8>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
-        default: rc = launch_spill<9>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist); break;
+        case 5: rc = launch_count<5>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
+        case 6: rc = launch_count<6>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
+        case 7: rc = launch_count<7>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
+        case 8: rc = launch_spill<8>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
+        default: rc = launch_spill<9>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
     }
     if (rc) return rc;
     hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, d_offs, d_lens,
                        nsamples, parts, ctx->d_wavephase, d_status);
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
+}
+
+int vk_count_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                    uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status) {
+    return count_impl(ctx, d_fastq, offsets, lengths, nsamples, k, parts_per_sample, d_hist, d_status, nullptr,
+                      nullptr, nullptr);
+}
+
+int vk_count_sampled_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                            uint32_t nsamples, int k, uint32_t parts_per_sample, const uint64_t* seeds,
+                            const uint64_t* thresholds, uint32_t* d_hist, uint32_t* d_status, uint64_t* d_sites) {
+    if (!seeds || !thresholds) return VK_EINVAL;
+    for (uint32_t i = 0; i < nsamples; ++i)
+        if (thresholds[i] > (1ull << 32)) return VK_EINVAL;
+    return count_impl(ctx, d_fastq, offsets, lengths, nsamples, k, parts_per_sample, d_hist, d_status, seeds,
+                      thresholds, d_sites);
 }
 
 int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int k, uint8_t* d_img) {

@@ -169,6 +169,31 @@ class ImageEngine:
         _capi.check(self.ctx, st, "vk_count_device")
         return hist, status
 
+    def count_sampled(self, fastq, offsets, lengths, seeds, thresholds, parts=0, hist=None, status=None,
+                      sites=None):
+        """K1 over a pseudo-random subset of each sample's reads (vk_count_sampled_device):
+        seeds / thresholds are per-sample host arrays (threshold = fraction * 2^32, 2^32 = all).
+        Returns (hist [n, 4^k], status [n], sites int64 [n, 2] = (bytes of all sequence lines,
+        bytes of the sequence lines of the reads taken))."""
+        torch = _torch()
+        offs, lens = self._desc(offsets, lengths)
+        n = len(offs)
+        seeds = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (n,)))
+        thr = np.ascontiguousarray(np.broadcast_to(np.asarray(thresholds, dtype=np.uint64), (n,)))
+        if hist is None:
+            hist = torch.empty((n, self.ncode), dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if sites is None:
+            sites = torch.empty((n, 2), dtype=torch.int64, device=self.device)
+        u64p = C.POINTER(C.c_uint64)
+        st = self.L.vk_count_sampled_device(self.ctx, self._ptr(fastq), offs.ctypes.data_as(u64p),
+                                            lens.ctypes.data_as(u64p), n, self.k, parts, seeds.ctypes.data_as(u64p),
+                                            thr.ctypes.data_as(u64p), self._ptr(hist), self._ptr(status),
+                                            self._ptr(sites))
+        _capi.check(self.ctx, st, "vk_count_sampled_device")
+        return hist, status, sites
+
     def images(self, hist, img=None):
         """K2: uint8 images [n, side, side] from histograms [n, 4^k]."""
         torch = _torch()

@@ -96,3 +96,89 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     if engine is None:
         eng.close()
     return stats
+
+
+def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp=None, is_query=False, seeds=None,
+                    labels=None, base_sd=None, subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=2 << 30,
+                    io_threads=8, engine=None, verbose=False):
+    """Steps C+D+E of run_clean2img (commands/image.py:1006-1127) for cleaned, UNSPLIT read files
+    `<sample>.fq[.gz]` (the reference's `<int_folder>/clean_reads/`): the 1-2-5 ladder of subsamples
+    is drawn on the GPU (subsample.ladder_counts) instead of writing one file per size with
+    reformat.sh, and every step becomes `<sample>@<bp>K+<mapping>+k<k>.png`.
+
+    seeds: {sample: int} (default 0).  Returns {sample: OrderedDict(stats)} with the reference's
+    keys `splitting_bp_per_file`, `<k>mer_counting_time`, `k<k>_img_time`, or `failed_step`."""
+    import os
+
+    import torch
+
+    from .engine import ImageEngine
+    from .subsample import ladder_counts, split_name
+    files = [Path(f) for f in files]
+    labels, base_sd, seeds = labels or {}, base_sd or {}, seeds or {}
+    mine = [files[i] for i in shard_indices(len(files), rank, world)]
+    eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
+    outdir = Path(outdir)
+    outdir.mkdir(parents=True, exist_ok=True)
+    stats = OrderedDict()
+    pool = ThreadPoolExecutor(io_threads)
+    pending = []
+    i = 0
+    while i < len(mine):
+        batch, nbytes = [], 0
+        t0 = time.perf_counter()
+        for f in mine[i:]:
+            sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
+            if batch and nbytes + sz > batch_bytes:
+                break
+            batch.append(f)
+            nbytes += sz
+        i += len(batch)
+        names = [str(f.name.removesuffix("".join(f.suffixes))) for f in batch]
+        dev, offs, lens = eng.upload_files(batch, pool)
+        recs = []
+        # one seed per launch: samples with different seeds go in separate calls
+        by_seed = OrderedDict()
+        for j, s in enumerate(names):
+            by_seed.setdefault(int(seeds.get(s, 0)), []).append(j)
+        recs = [None] * len(batch)
+        for seed, idx in by_seed.items():
+            for j, r in zip(idx, ladder_counts(eng, dev, offs[idx], lens[idx], seed=seed, min_bp=min_bp,
+                                               max_bp=max_bp, is_query=is_query)):
+                recs[j] = r
+        t1 = time.perf_counter()
+        flat = [(j, bp, h) for j, r in enumerate(recs) for bp, h, _ in r["steps"]]
+        imgs = eng.images(torch.stack([h for _, _, h in flat])).cpu().numpy() if flat else []
+        nz = [bool((h != 0).any().item()) for _, _, h in flat]
+        t2 = time.perf_counter()
+        for j, s in enumerate(names):
+            st = stats.setdefault(s, OrderedDict())
+            if recs[j]["error"]:
+                eprint("SPLIT FAIL:", batch[j], "-", recs[j]["error"])
+                st["failed_step"] = "split"
+                continue
+            st["splitting_time"] = (t1 - t0) / len(batch)
+            st["splitting_bp_per_file"] = ",".join(str(bp) for bp, _, _ in recs[j]["steps"])
+            st[str(k) + "mer_counting_time"] = (t1 - t0) / len(batch)
+        for n, (j, bp, _) in enumerate(flat):
+            s = names[j]
+            if not nz[n]:
+                eprint("IMAGE FAIL:", split_name(s, bp))
+                stats[s]["failed_step"] = "image"
+                continue
+            name = png_name(split_name(s, bp) + "+k" + str(k) + ".fq.h5", mapping_code)
+            d = shard_folder(outdir, name, subfolder_levels)
+            d.mkdir(parents=True, exist_ok=True)
+            pending.append((s, time.perf_counter(),
+                            pool.submit(write_png, imgs[n].copy(), d / name, labels.get(s, []), base_sd.get(s, 0),
+                                        QUAL_THRESH, mapping_code)))
+        if verbose:
+            eprint(f"batch of {len(batch)} samples, {nbytes} bytes: upload+ladder {t1 - t0:.3f}s images {t2 - t1:.3f}s")
+    for s, t, fut in pending:
+        fut.result()
+        key = "k" + str(k) + "_img_time"
+        stats[s][key] = stats[s].get(key, 0) + (time.perf_counter() - t)
+    pool.shutdown()
+    if engine is None:
+        eng.close()
+    return stats

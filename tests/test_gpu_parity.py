@@ -230,3 +230,29 @@ def test_giant_sample_ranges_sum_to_the_whole(engines):
         assert status == 0
         total += hist
     assert np.array_equal(total, want)
+
+
+@pytest.mark.parametrize("k,mapping", [(8, "cgr"), (8, "varKode"), (9, "cgr"), (9, "varKode")])
+def test_large_image_order_statistics_by_counting(engines, k, mapping):
+    """Large images take vk_image_count_kernel (counted ranks + a sorted list of outliers) with
+    vk_image_kernel's sort as the fallback: every regime against the oracle's sort."""
+    import torch
+    eng = engines(k, mapping)
+    n = 4 ** k
+    rng = np.random.default_rng(k * 7 + len(mapping))
+    cases = {
+        "small": rng.poisson(500, n),                                              # one counting pass
+        "both_halves": rng.integers(0, 33000, n),                                  # values on both sides of 32768
+        "few_outliers": np.where(rng.random(n) < 0.001, rng.integers(10 ** 5, 10 ** 9, n), rng.poisson(900, n)),
+        "many_outliers": np.where(rng.random(n) < 0.7, rng.integers(40000, 2 ** 30, n), rng.poisson(50, n)),  # -> sort
+        "empty": np.zeros(n, dtype=np.int64),                                      # every pixel the same value
+        "edges": rng.choice(np.array([0, 16382, 16383, 16384, 32766, 32767, 32768, 65534, 65535, 65536]), n),
+        "huge": rng.integers(2 ** 30 - 5, 2 ** 30, n),                             # all values listed, none counted
+    }
+    names = list(cases)
+    fwd = np.stack([np.ascontiguousarray(cases[c], dtype=np.uint32) for c in names])
+    img = eng.images(torch.from_numpy(fwd.view(np.int32)).cuda()).cpu().numpy()
+    lut, s = pixel_lut(k, mapping), side(k, mapping)
+    for i, name in enumerate(names):
+        want = oracle.image(oracle.strand_merge(fwd[i], k), k, lut, s * s)
+        assert np.array_equal(img[i].ravel(), want), name

@@ -854,12 +854,15 @@ __device__ void bitonic_tile(uint32_t* tile, uint32_t tlen, uint32_t gbase, uint
 }
 
 // One workgroup per sample.  scratch: [nsamples][2][npad] u32 (val, sorted).
+// `only_if` (may be null): per-sample flags written by vk_image_count_kernel; a sample whose flag is 0
+// is already done.
 __global__ __launch_bounds__(kImgThreads) void vk_image_kernel(
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ pix, int k, uint32_t npix,
-    uint32_t npad, uint32_t* __restrict__ scratch, uint8_t* __restrict__ img) {
+    uint32_t npad, uint32_t* __restrict__ scratch, uint8_t* __restrict__ img, const uint32_t* __restrict__ only_if) {
     __shared__ uint32_t tile[kTile];
     __shared__ unsigned long long bins[256];
     const uint32_t s = blockIdx.x;
+    if (only_if && only_if[s] == 0u) return;  // uniform over the workgroup
     const uint32_t ncode = 1u << (2 * k);
     const uint32_t* h = hist + static_cast<uint64_t>(s) * ncode;
     uint32_t* val = scratch + static_cast<uint64_t>(s) * 2u * npad;
@@ -929,6 +932,131 @@ __global__ __launch_bounds__(kImgThreads) void vk_image_kernel(
         unsigned long long v = 256ull * val[p];
         // upper_bound over the non-decreasing bins; bins[0] = 256*min <= v, so the
         // answer lies in [1, 256]: 255 candidates to discard, 8 halvings
+        uint32_t lo = 1, hi = 256;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            uint32_t mid = (lo + hi) >> 1;
+            bool le = bins[mid] <= v;
+            lo = le ? mid + 1u : lo;
+            hi = le ? hi : mid;
+        }
+        out[p] = static_cast<uint8_t>(lo - 1u);
+    }
+}
+
+// K2 for large images (k = 8, 9: 65k..262k pixels): the 256 quantile cut points need 512 order
+// statistics, not a sorted array.  Pixel values below 2 x 32768 are COUNTED in a 32768-bin LDS
+// histogram (one pass per half), a prefix scan turns the counts into ranks, and every wanted rank is
+// looked up by binary search; the few larger values (outlier k-mers) are listed, sorted in LDS and
+// indexed directly.  Exact like the sort, ~40x shorter for one 512 x 512 image.  A sample
+// with more than 32768 values >= 65536 is left to vk_image_kernel (flag = 1).
+constexpr uint32_t kCountBins = 32768;
+
+__global__ __launch_bounds__(kImgThreads) void vk_image_count_kernel(
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ pix, int k, uint32_t npix,
+    uint32_t npad, uint32_t* __restrict__ scratch, uint8_t* __restrict__ img, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t cnt[kCountBins];
+    __shared__ unsigned long long bins[256];
+    __shared__ uint32_t order[512];   // [j] = a[i_j], [256 + j] = a[min(i_j + 1, npix - 1)]
+    __shared__ uint32_t wsum[kImgThreads / 64];
+    __shared__ uint32_t novf, any_hi;
+    const uint32_t s = blockIdx.x;
+    const uint32_t ncode = 1u << (2 * k);
+    const uint32_t* h = hist + static_cast<uint64_t>(s) * ncode;
+    uint32_t* val = scratch + static_cast<uint64_t>(s) * 2u * npad;
+    uint32_t* ovf = val + npad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    for (uint32_t i = tid; i < npad; i += kImgThreads) val[i] = 0u;
+    if (tid == 0) { novf = 0u; any_hi = 0u; }
+    __syncthreads();
+    for (uint32_t c = tid; c < ncode; c += kImgThreads) {  // strand merge + scatter, as in vk_image_kernel
+        uint32_t r = revcomp_code(c, k);
+        uint32_t tot = (r == c) ? h[c] : h[c] + h[r];
+        val[pix[c]] = tot + 1u;
+    }
+    __syncthreads();
+
+    uint32_t my_rank = 0;  // thread t < 512 looks up one order statistic
+    if (tid < 512) {
+        const unsigned long long pos = static_cast<unsigned long long>(tid & 255u) * (npix - 1u);
+        const uint32_t i = static_cast<uint32_t>(pos >> 8);
+        my_rank = (tid < 256) ? i : ((i + 1u < npix) ? i + 1u : npix - 1u);
+    }
+    uint32_t base = 0;  // values counted by earlier passes
+    for (uint32_t pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && any_hi == 0u) break;  // uniform: nothing in [32768, 65536)
+        for (uint32_t i = tid; i < kCountBins; i += kImgThreads) cnt[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = tid; i < npix; i += kImgThreads) {
+            const uint32_t v = val[i], hi = v >> 15;
+            if (hi == pass) {
+                atomicAdd(&cnt[v & (kCountBins - 1u)], 1u);
+            } else if (pass == 0) {
+                if (hi == 1u) {
+                    any_hi = 1u;
+                } else {
+                    const uint32_t at = atomicAdd(&novf, 1u);
+                    ovf[at] = v;  // at < npix <= npad
+                }
+            }
+        }
+        __syncthreads();
+        // inclusive scan of the counts, in place: 32 consecutive bins per thread
+        uint32_t local = 0;
+        const uint32_t b0 = tid * (kCountBins / kImgThreads);
+#pragma unroll 8
+        for (uint32_t b = 0; b < kCountBins / kImgThreads; ++b) local += cnt[b0 + b];
+        const uint32_t incl = wave_inclusive_sum(local);
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - local;
+        for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+        uint32_t run = before;
+#pragma unroll 8
+        for (uint32_t b = 0; b < kCountBins / kImgThreads; ++b) {
+            run += cnt[b0 + b];
+            cnt[b0 + b] = run;
+        }
+        __syncthreads();
+        const uint32_t total = cnt[kCountBins - 1u];
+        if (tid < 512 && my_rank >= base && my_rank - base < total) {
+            const uint32_t r = my_rank - base;  // smallest bin with cumulative count > r
+            uint32_t lo = 0, hi = kCountBins - 1u;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cnt[mid] > r) hi = mid; else lo = mid + 1u;
+            }
+            order[tid] = pass * kCountBins + lo;
+        }
+        base += total;
+        __syncthreads();
+    }
+    const uint32_t n_over = novf;
+    if (n_over > kCountBins) {  // uniform: too many large values for LDS, the sort kernel takes over
+        if (tid == 0) flags[s] = 1u;
+        return;
+    }
+    if (n_over > 0u) {
+        uint32_t tlen = 2;
+        while (tlen < n_over) tlen <<= 1;
+        for (uint32_t i = tid; i < tlen; i += kImgThreads) cnt[i] = (i < n_over) ? ovf[i] : 0xFFFFFFFFu;
+        __syncthreads();
+        bitonic_tile(cnt, tlen, 0u, 2u, tlen, false);
+        if (tid < 512 && my_rank >= base) order[tid] = cnt[my_rank - base];
+        __syncthreads();
+    }
+    if (tid == 0) flags[s] = 0u;
+    if (tid < 256) {
+        const unsigned long long pos = static_cast<unsigned long long>(tid) * (npix - 1u);
+        const uint32_t g = static_cast<uint32_t>(pos & 255u);
+        const uint32_t ai = order[tid], aj = order[256u + tid];
+        bins[tid] = 256ull * ai + static_cast<unsigned long long>(aj - ai) * g;
+    }
+    __syncthreads();
+    uint8_t* out = img + static_cast<uint64_t>(s) * npix;
+    for (uint32_t p = tid; p < npix; p += kImgThreads) {
+        unsigned long long v = 256ull * val[p];
         uint32_t lo = 1, hi = 256;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1154,6 +1282,7 @@ struct vk_ctx {
     uint32_t* d_status1 = nullptr;
     uint8_t* d_img1 = nullptr;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+    bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
 };
 
 #define VK_HIP(ctx, call)                     \
@@ -1321,6 +1450,10 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
     vk_ctx* ctx = new (std::nothrow) vk_ctx();
     if (!ctx) return VK_ENOMEM;
     ctx->device = device;
+    {
+        const char* e = getenv("VKIMG_IMAGE_SORT_ONLY");
+        ctx->image_sort_only = e && e[0] == '1';
+    }
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return VK_EHIP; }
     if (!own_stream) {
         ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the device's default stream
@@ -1453,11 +1586,21 @@ int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int 
     VK_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t npix = ctx->npix[k];
     const uint32_t npad = npad_of(npix);
+    const size_t work = static_cast<size_t>(nsamples) * 2u * npad * sizeof(uint32_t);
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_scratch), &ctx->scratch_cap,
-                    static_cast<size_t>(nsamples) * 2u * npad * sizeof(uint32_t));
+                    work + static_cast<size_t>(nsamples) * sizeof(uint32_t));
     if (rc) return rc;
+    const uint32_t* gate = nullptr;
+    if (npad > kTile && !ctx->image_sort_only) {
+        // large images: order statistics by counting; samples it cannot finish are flagged for the sort
+        uint32_t* flags = ctx->d_scratch + work / sizeof(uint32_t);
+        hipLaunchKernelGGL(vk_image_count_kernel, dim3(nsamples), dim3(kImgThreads), 0, ctx->stream, d_hist,
+                           ctx->d_pix[k], k, npix, npad, ctx->d_scratch, d_img, flags);
+        VK_HIP(ctx, hipGetLastError());
+        gate = flags;
+    }
     hipLaunchKernelGGL(vk_image_kernel, dim3(nsamples), dim3(kImgThreads), 0, ctx->stream, d_hist, ctx->d_pix[k], k,
-                       npix, npad, ctx->d_scratch, d_img);
+                       npix, npad, ctx->d_scratch, d_img, gate);
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
 }

@@ -82,13 +82,25 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
         list(ex.map(one, range(nsamp)))
     dt = time.perf_counter() - t0
     out = {"value": nsamp * bases_per_sample / dt / 1e9, "unit": "Gbases/s", "cores": cores,
-           "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9,
+           "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9, "cpu_model": cpu_model(),
+           "host_cpus": os.cpu_count(),
            "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
                      f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
     ref = dsk_reference(bufs[0], args, cores)
     if ref:
         out["dsk"] = ref
     return out
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def dsk_argv(threads, k, infile, tmpdir, outpath):

@@ -34,11 +34,14 @@ __global__ __launch_bounds__(1024) void k(uint32_t* out, int iters) {
             else if (MODE == 4) a = (r & 16383 & ~31u) | (lane & 31);
             else if (MODE == 5) a = (i * 8 + j) & 16383;
             else if (MODE == 7) a = r & 255;
+            else if (MODE == 12) a = r & 15;
+            else if (MODE == 13) a = ((r & 15) << 2) | (lane >> 4);
+            else if (MODE == 14) a = ((r & 15) << 1) | (lane >> 5);
             else a = r & 16383;
-            if (MODE == 2) on = ((s >> 3) & 127) < 60;
+            if (MODE == 2 || MODE >= 12) on = ((s >> 3) & 127) < 60;
             if (MODE == 6) on = ((s >> 3) & 3) == 0;
             if (on) {
-                if (MODE == 3) acc += atomicAdd(&h[a], 1u);
+                if (MODE == 3 || MODE >= 12) acc += atomicAdd(&h[a], 1u);
                 else atomicAdd(&h[a], 1u);
             }
         }
@@ -77,6 +80,9 @@ int main() {
     run<3>(d, "random bins, returning", 1.0);
     run<5>(d, "one bin for all lanes", 1.0);
     run<7>(d, "random within 256 bins", 1.0);
+    run<12>(d, "16 counters, returning, 47% lanes", 0.47);
+    run<14>(d, "32 counters (2 lane groups), rtn, 47%", 0.47);
+    run<13>(d, "64 counters (4 lane groups), rtn, 47%", 0.47);
     run<8>(d, "random bins, fixed 47% of lanes", 0.47);
     run<9>(d, "random bins, lanes 0..31", 0.5);
     run<11>(d, "random bins, even lanes", 0.5);

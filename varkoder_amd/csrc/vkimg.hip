@@ -570,13 +570,14 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
 
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
 // 4^K u32 counters do not fit LDS.  Pass A streams the FASTQ exactly like vk_count_kernel but
-// appends every window's low 2K-4 bits to one of 16 wave-private LDS queues chosen by the
-// window's top 4 bits, and drains full 64-entry blocks (128 B) into per-(sample, queue) bucket
-// streams in HBM.  The drain handles all 16 queues at once, four lanes per queue; block runs are
-// reserved 32 at a time with one global atomic, unused run tails are padded with 0xFFFF.  Pass B
-// gives every (sample, queue) one workgroup that replays its stream into a 4^K/16-bin LDS
-// histogram.  Entries that cannot be queued or whose bucket is full are counted with global
-// atomics on the spot: slower, still exact.
+// appends the windows, two at a time (see entry_raw), to one of 16 wave-private LDS queues chosen
+// by the two bases both windows of a pair share, and drains full 64-entry blocks (128 B) into
+// per-(sample, queue) bucket streams in HBM.  The drain handles all 16 queues at once, four lanes
+// per queue; block runs are reserved 32 at a time with one global atomic, unused run tails are
+// padded with 0xFFFF.  Pass B gives every (sample, queue) one workgroup that replays its stream into
+// a 2 x 4^K/16-bin LDS histogram (one half per entry type) and adds it to the global histogram.
+// Pairs that cannot be queued or whose bucket is full are counted with global atomics on the spot:
+// slower, still exact.
 constexpr uint32_t kQueues = 16;         // queues per wave = bucket streams per sample
 constexpr uint32_t kQueueCap = 128;      // u16 entries per queue (two blocks)
 constexpr uint32_t kBlockEntries = 64;   // u16 entries per 128-byte bucket block
@@ -587,6 +588,22 @@ struct BucketParams {
     uint32_t* buckets;   // [nsamples][16][cap_blocks * 32] dwords
     uint32_t cap_blocks; // multiple of kRunBlocks
 };
+
+// Bucket entries (u16, 0xFFFF = padding).  Two windows that end at neighbouring positions p, p + 1
+// (p even) share the bases p-1 and p; those four bits are the queue number q of BOTH, so one
+// returning LDS atomic and one 32-bit store queue the pair.  LB = 2K - 4 bits remain per window:
+//   low half,  type 0 (window ending at p):     bases p-K+1 .. p-2
+//   high half, type 1 (window ending at p + 1): bases p-K+2 .. p-2, then base p+1
+// The type is the half of the dword the entry sits in (blocks move as whole 128-byte units, so the
+// halves never mix).  entry_raw rebuilds the raw window field (first base least significant) from
+// rest | type << LB.
+template <int K>
+__device__ __forceinline__ uint32_t entry_raw(uint32_t q, uint32_t e) {
+    constexpr uint32_t LB = 2 * K - 4;
+    const uint32_t rest = e & ((1u << LB) - 1u);
+    if ((e >> LB) == 0u) return (q << LB) | rest;
+    return (rest & ((1u << (LB - 2)) - 1u)) | (q << (LB - 2)) | ((rest >> (LB - 2)) << (2 * K - 2));
+}
 
 __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
@@ -667,8 +684,8 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
-                        if (lo != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << LB) | lo, K)], 1u);
-                        if (hi != 0xFFFFu) atomicAdd(&hist_s[pair_reverse((q << LB) | hi, K)], 1u);
+                        if (lo != 0xFFFFu) atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, lo), K)], 1u);
+                        if (hi != 0xFFFFu) atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, hi | (1u << LB)), K)], 1u);
                     }
                 }
             }
@@ -686,7 +703,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             qbuf[wave][q * (kQueueCap / 8) + sub * 2u + 1u] = k1;
         }
         if (nb && sub == 0) {
-            qcnt[wave][q] = n - nb * kBlockEntries;
+            qcnt[wave][q] = 2u * (n - nb * kBlockEntries);
             runbase[wave][q] = store ? base + nb : base;
             runleft[wave][q] = store ? left - nb : 0u;
         }
@@ -695,22 +712,65 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
 
     uint32_t ph_start = 0, ph_end = 0;
     if (!wr.empty) {
-        auto emit = [&](uint32_t a4) __attribute__((always_inline)) {
-            const uint32_t raw = a4 >> 2;
-            const uint32_t qq = raw >> LB, loc = raw & LMASK;
-            const uint32_t idx = atomicAdd(&qcnt[wave][qq], 1u);  // returning LDS atomic
-            if (idx < kQueueCap) q16[qq * kQueueCap + idx] = static_cast<uint16_t>(loc);
-            else atomicAdd(&hist_s[pair_reverse(raw, K)], 1u);    // queue full: exact slow path
+        // LDS byte addresses: the wave's 16 counters (which count BYTES, 4 per pair) and its queues
+        auto lds_addr = [](const void* p) {
+            return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
+        };
+        const uint32_t cnt_base = lds_addr(&qcnt[wave][0]);
+        // data address of queue qq = (counter address << 6) + data_skew, counters being 4 B apart
+        const uint32_t data_skew = lds_addr(&qbuf[wave][0]) - (cnt_base << 6);
+        // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
+        // `bit + 2` = the window ending at p / p + 1 is countable.  A missing partner becomes padding.
+        // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
+        // `bit + 2` = the window ending at p / p + 1 is countable.  A missing partner becomes padding.
+        // (Issuing the atomics of four pairs back to back behind one wait was measured: 3 % slower,
+        // the loop is bound by VALU + SALU issue, not by the LDS round trip.)
+        auto emit_pair = [&](uint32_t x, uint32_t okw, int bit) __attribute__((always_inline)) {
+            constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
+            const uint32_t caddr = cnt_base + 4u * __builtin_amdgcn_ubfe(x, LB, 4);
+            uint32_t at;  // returning LDS atomic on the queue's byte counter
+            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(at) : "v"(caddr), "v"(4u) : "memory");
+            const uint32_t rest_a = x & LMASK;
+            const uint32_t rest_b = __builtin_amdgcn_ubfe(x, 2, LB - 2) | (__builtin_amdgcn_ubfe(x, 2 * K, 2) << (LB - 2));
+            // all ones where the window counts: 0xFFFF in the half of a window that does not
+            const uint32_t keep0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(okw), bit, 1));
+            const uint32_t keep1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(okw), bit + 2, 1));
+            const uint32_t w = (rest_a | (rest_b << 16)) | ~__builtin_amdgcn_perm(keep1, keep0, 0x05040100u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(at) : : "memory");
+            if (at < 2u * kQueueCap) {
+                const uint32_t daddr = (caddr << 6) + data_skew + at;
+                asm volatile("ds_write_b32 %0, %1" : : "v"(daddr), "v"(w) : "memory");
+            } else {  // queue full: exact slow path
+                if (keep0) atomicAdd(&hist_s[pair_reverse(x & FMASK, K)], 1u);
+                if (keep1) atomicAdd(&hist_s[pair_reverse((x >> 2) & FMASK, K)], 1u);
+            }
         };
         auto after_group = [&]() __attribute__((always_inline)) {
             wave_lds_fence();
-            uint32_t n = qcnt[wave][q];
+            uint32_t n = qcnt[wave][q] >> 1;  // bytes -> entries
             if (n > kQueueCap) n = kQueueCap;
             const uint32_t nb = n / kBlockEntries;
             if (__any(nb != 0u)) drain_all(n, nb);
         };
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
-            vkl::windows<K>(ch, C, ok, emit, after_group);
+            const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int p = 16 * g + 2 * j;  // windows ending at p and p + 1
+                    if (ok[g] & (5u << (4 * j))) {
+                        const int o = 32 + 2 * (p - K + 1);  // bit offset of base p-K+1 in [ch | C]
+                        const int word = o >> 5, sh = o & 31;
+                        uint32_t x;
+                        if (sh == 0) x = v[word];
+                        else if (word == 4) x = v[4] >> sh;  // the last pair ends exactly at bit 160
+                        else x = vkl::alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+                        emit_pair(x, ok[g], 4 * j);
+                    }
+                }
+                after_group();  // 16 positions of every lane done: drain the queues that hold a block
+            }
         };
         SubWave sw = {0, 0, 0, 0};
         if constexpr (SUB) {
@@ -721,7 +781,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
         // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();
-        uint32_t n = qcnt[wave][q];
+        uint32_t n = qcnt[wave][q] >> 1;
         if (n > kQueueCap) n = kQueueCap;
         const uint32_t nb = (n + kBlockEntries - 1) / kBlockEntries;
         for (uint32_t e = n + sub; e < nb * kBlockEntries; e += 4) q16[q * kQueueCap + e] = 0xFFFFu;
@@ -744,7 +804,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
                                                                          uint32_t* __restrict__ hist_out) {
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr uint32_t LB = 2 * K - 4;
-    constexpr uint32_t BINS = 1u << LB;
+    constexpr uint32_t BINS = 2u << LB;  // indexed by the entry: type bit | rest
     __shared__ uint32_t hist[BINS];
     const uint32_t s = blockIdx.x / kQueues, q = blockIdx.x % kQueues;
     const uint32_t tid = threadIdx.x;
@@ -755,21 +815,32 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     const uint4* src = reinterpret_cast<const uint4*>(bp.buckets + (static_cast<uint64_t>(s) * kQueues + q) *
                                                                        bp.cap_blocks * 32u);
     const uint64_t n16 = static_cast<uint64_t>(nblk) * 8u;  // 16-byte groups
-    for (uint64_t i = tid; i < n16; i += kCountThreads) {
-        const uint4 v = src[i];
+    auto tally = [&](const uint4& v) __attribute__((always_inline)) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
             if (lo != 0xFFFFu) atomicAdd(&hist[lo], 1u);
-            if (hi != 0xFFFFu) atomicAdd(&hist[hi], 1u);
+            if (hi != 0xFFFFu) atomicAdd(&hist[hi + (1u << LB)], 1u);  // the high half holds the type-1 entries
         }
+    };
+    // four 16-byte loads in flight per thread: the stream is read once, latency is all there is to hide
+    uint64_t i = tid;
+    for (; i + 3ull * kCountThreads < n16; i += 4ull * kCountThreads) {
+        const uint4 v0 = src[i], v1 = src[i + kCountThreads], v2 = src[i + 2ull * kCountThreads],
+                    v3 = src[i + 3ull * kCountThreads];
+        tally(v0);
+        tally(v1);
+        tally(v2);
+        tally(v3);
     }
+    for (; i < n16; i += kCountThreads) tally(src[i]);
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
     for (uint32_t i = tid; i < BINS; i += kCountThreads) {
         const uint32_t v = hist[i];
-        if (v) out[pair_reverse((q << LB) | i, K)] += v;  // this workgroup owns these codes now
+        // type-1 entries of this queue and type-0 entries of another can name the same code
+        if (v) atomicAdd(&out[pair_reverse(entry_raw<K>(q, i), K)], v);
     }
 }
 

@@ -731,10 +731,14 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             uint32_t at;  // returning LDS atomic on the queue's byte counter
             asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(at) : "v"(caddr), "v"(4u) : "memory");
             const uint32_t rest_a = x & LMASK;
-            const uint32_t rest_b = __builtin_amdgcn_ubfe(x, 2, LB - 2) | (__builtin_amdgcn_ubfe(x, 2 * K, 2) << (LB - 2));
+            // bit-field extracts spelled out: hipcc turns the builtins back into shift pairs here
+            uint32_t low_b, top_b, keep0, keep1;
+            asm("v_bfe_u32 %0, %1, 2, %2" : "=v"(low_b) : "v"(x), "n"(LB - 2));
+            asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(top_b) : "v"(x), "n"(2 * K));
+            const uint32_t rest_b = (top_b << (LB - 2)) | low_b;
             // all ones where the window counts: 0xFFFF in the half of a window that does not
-            const uint32_t keep0 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(okw), bit, 1));
-            const uint32_t keep1 = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(okw), bit + 2, 1));
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep0) : "v"(okw), "n"(bit));
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep1) : "v"(okw), "n"(bit + 2));
             const uint32_t w = (rest_a | (rest_b << 16)) | ~__builtin_amdgcn_perm(keep1, keep0, 0x05040100u);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(at) : : "memory");
             if (at < 2u * kQueueCap) {

@@ -20,9 +20,10 @@ def hipcc_path():
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INC, "vkimg.h")),
-                 os.path.getmtime(os.path.join(HERE, "csrc", "vk_lane.h")))
-    return os.path.getmtime(OUT) < newest
+    csrc = os.path.join(HERE, "csrc")
+    deps = [os.path.join(INC, "vkimg.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc)
+                                             if f.endswith((".hip", ".h"))]
+    return os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps)
 
 
 def build_hip(force=False, verbose=False):

@@ -185,7 +185,7 @@ __device__ __forceinline__ WaveRange wave_range(uint64_t len, uint32_t parts, ui
 
 // One wavefront streams the FASTQ bytes [w0, w1) of a sample and hands every 64-byte block's code
 // string and countable-window mask to windows(ch, C[4], ok[4]) (raw fields: first base least
-// significant, vk_lane.h).  `st` is the wave's private 4 KiB LDS slot,
+// significant, vk_lane.h).  `scratch` is a few wave-private LDS words for the range-start sync,
 // below/above the shared mask tables.  Returns the line phase at w0 and at w1.
 // Window loop of the LDS-histogram kernels (K <= 7): same arithmetic as vkl::windows<K>, with the
 // predicated histogram update written out.  hipcc lowers `if (carry) atomicAdd(...)` to
@@ -315,10 +315,10 @@ __device__ unsigned long long g_vk_stamps[8];
 
 template <int K, bool SUB, typename Windows>
 __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
-                                            uint64_t w1, uint4* st, const uint4* below, const uint4* above,
+                                            uint64_t w1, uint64_t* scratch, const uint4* below, const uint4* above,
                                             int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end,
                                             SubWave& sw) {
-    const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(st), lane) : 0u;
+    const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, scratch, lane) : 0u;
     ph_start = ph0;
 
     // Pieces start one 64-byte block BEFORE the range: lane 0 of piece 0 (the "pre-block")
@@ -327,22 +327,25 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
     const long long o0 = static_cast<long long>(w0) - 64;
     const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
     uint4 r0, r1, r2, r3;
-    // A piece that lies wholly inside [0, w1) (all but the first and last of a range) is
-    // loaded with four unguarded 16-byte loads off one address; edge pieces zero-fill.
+    // Every lane loads ITS 64 contiguous bytes (four 16-byte loads): one instruction touches 64
+    // cache lines, but the four together use them completely and the lines stay in the CU's L1
+    // between them -- measured HBM traffic equals the file size, and the former LDS transpose
+    // (coalesced rows in, lane blocks out: 8 LDS instructions and 64 KiB of LDS) bought nothing.
+    // A piece wholly inside [0, w1) is loaded unguarded; edge pieces zero-fill.
     auto load_piece = [&](uint64_t piece) {
         const long long pb = o0 + static_cast<long long>(piece) * kPiece;
         if (pb >= 0 && static_cast<uint64_t>(pb) + kPiece <= w1) {  // wave-uniform
-            const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + lane;
+            const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + 4 * lane;
             r0 = g[0];
-            r1 = g[64];
-            r2 = g[128];
-            r3 = g[192];
+            r1 = g[1];
+            r2 = g[2];
+            r3 = g[3];
         } else {
-            const long long p = pb + static_cast<long long>(lane) * 16;
+            const long long p = pb + static_cast<long long>(lane) * 64;
             r0 = load_granule_s(sbase, p, w1);
-            r1 = load_granule_s(sbase, p + 1024, w1);
-            r2 = load_granule_s(sbase, p + 2048, w1);
-            r3 = load_granule_s(sbase, p + 3072, w1);
+            r1 = load_granule_s(sbase, p + 16, w1);
+            r2 = load_granule_s(sbase, p + 32, w1);
+            r3 = load_granule_s(sbase, p + 48, w1);
         }
     };
     load_piece(0);
@@ -366,15 +369,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
 #endif
     for (uint64_t it = 0; it < npieces; ++it) {
         VK_STAMP(t0);
-        // transpose through LDS: coalesced rows in, 64 contiguous bytes per lane out
-        wave_lds_fence();
-        st[lane] = r0;
-        st[64 + lane] = r1;
-        st[128 + lane] = r2;
-        st[192 + lane] = r3;
-        wave_lds_fence();
-        uint4 q0 = st[lane * 4 + 0], q1 = st[lane * 4 + 1], q2 = st[lane * 4 + 2], q3 = st[lane * 4 + 3];
-        wave_lds_fence();
+        const uint4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;  // this lane's 64 bytes
         if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
         const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -492,7 +487,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     // The LDS histogram is indexed by the RAW packed field (first base least
     // significant, see vk_lane.h); the flush un-reverses to the ABI's code order.
     __shared__ uint32_t hist[NCODE];
-    __shared__ uint4 stage[kWaves][kPiece / 16];
+    __shared__ uint64_t scratch[kWaves][8];  // sync_phase: newline positions after a range start
     __shared__ uint4 below[66];  // below[q] = bits [0, 2q) of a 128-bit string
     __shared__ uint4 above[66];  // above[q] = ~below[q]
 
@@ -522,7 +517,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
     }
@@ -592,7 +587,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     constexpr uint32_t LMASK = (1u << LB) - 1u;
     static_assert(LB <= 15, "entries are u16 with 0xFFFF as padding");
 
-    __shared__ uint4 stage[kWaves][kPiece / 16];
+    __shared__ uint64_t scratch[kWaves][8];  // sync_phase: newline positions after a range start
     __shared__ uint4 below[66];
     __shared__ uint4 above[66];
     __shared__ uint4 qbuf[kWaves][kQueues * kQueueCap / 8];  // u16 entries, eight per uint4
@@ -754,7 +749,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &stage[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
         // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();

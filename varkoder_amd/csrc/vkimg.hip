@@ -13,10 +13,9 @@
 // Design notes live in DESIGN.md; the short version for K1:
 //   * one 1024-thread workgroup per (sample, byte-range part);
 //     its 16 wavefronts run WITHOUT workgroup barriers in steady state: every
-//     wave streams its own contiguous byte range in 4 KiB pieces (4 coalesced
-//     16-B loads per lane, prefetched one piece ahead), transposes the piece
-//     through a private 4 KiB LDS slot so that each lane owns 64 contiguous
-//     bytes, and classifies them with 32-bit SWAR arithmetic (vk_lane.h);
+//     wave streams its own contiguous byte range in 4 KiB pieces (every lane loads its
+//     own 64 contiguous bytes, four 16-B loads, prefetched one piece ahead)
+//     and classifies them with 32-bit SWAR arithmetic (vk_lane.h);
 //   * FASTQ line phase (header/sequence/plus/quality) comes from a wave-level
 //     prefix sum of newline counts; the phase at a range start is recovered
 //     locally from the '@' / '+' framing, so byte ranges are independent;
@@ -135,7 +134,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                    ctx->stream));
     ctx->last_grid = grid;
     ctx->last_block = kCountThreads;
-    ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * kPiece + 2 * 66 * 16;
+    ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * 64 + 2 * 66 * 16;
     if (sub)
         hipLaunchKernelGGL((vk_count_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, *sub);
@@ -175,7 +174,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     bp.cap_blocks = static_cast<uint32_t>(cap);
     VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
     ctx->last_block = kCountThreads;
-    ctx->last_lds = kWaves * kPiece + 2 * 66 * 16 + kWaves * kQueues * kQueueCap * 2 + 3 * kWaves * kQueues * 4;
+    ctx->last_lds = kWaves * 64 + 2 * 66 * 16 + kWaves * kQueues * kQueueCap * 2 + 3 * kWaves * kQueues * 4;
     for (uint32_t s0 = 0; s0 < nsamples; s0 += batch) {
         const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
         VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * kQueues * sizeof(uint32_t), ctx->stream));

@@ -370,13 +370,15 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
     for (uint64_t it = 0; it < npieces; ++it) {
         VK_STAMP(t0);
         const uint4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;  // this lane's 64 bytes
-        if (it + 1 < npieces) load_piece(it + 1);  // prefetch the next piece under the SWAR work
         const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
         VK_STAMP(t1);
         vkl::LaneBits lb;
         const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
 
+        // prefetch the next piece under the rest of the work; the bytes of this one are consumed, so
+        // the loads land in the same registers
+        if (it + 1 < npieces) load_piece(it + 1);
         VK_STAMP(t2);
         // newline prefix over the wave -> line phase at the start of each lane's block
         const uint32_t incl = wave_inclusive_sum(c);

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
 // 4^K u32 counters do not fit LDS.  Pass A streams the FASTQ exactly like vk_count_kernel but
 // appends the windows, two at a time (see entry_raw), to one of 16 wave-private LDS queues chosen
-// by the two bases both windows of a pair share, and drains full 64-entry blocks (128 B) into
+// by the two bases both windows of a pair share, and once per piece drains full 64-entry blocks (128 B) into
 // per-(sample, queue) bucket streams in HBM.  The drain handles all 16 queues at once, four lanes
 // per queue; block runs are reserved 32 at a time with one global atomic, unused run tails are
 // padded with 0xFFFF.  Pass B gives every (sample, queue) one workgroup that replays its stream into
@@ -549,7 +549,9 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
 // Pairs that cannot be queued or whose bucket is full are counted with global atomics on the spot:
 // slower, still exact.
 constexpr uint32_t kQueues = 16;         // queues per wave = bucket streams per sample
-constexpr uint32_t kQueueCap = 128;      // u16 entries per queue (two blocks)
+constexpr uint32_t kQueueCap = 256;      // u16 entries per queue (four blocks)
+constexpr uint32_t kQueueBlocks = 4;     // kQueueCap / kBlockEntries
+constexpr uint32_t kQueueShift = 7;      // log2(bytes per queue / bytes per counter)
 constexpr uint32_t kBlockEntries = 64;   // u16 entries per 128-byte bucket block
 constexpr uint32_t kRunBlocks = 32;      // blocks reserved per global atomic
 
@@ -628,10 +630,12 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     auto drain_all = [&](uint32_t n, uint32_t nb) __attribute__((always_inline)) {
         uint32_t base = runbase[wave][q], left = runleft[wave][q];
         const bool need = nb > left;
-        if (need && left) {  // the rest of the old run (fewer than nb <= 2 blocks) stays padding
+        if (need) {  // the rest of the old run (fewer than nb <= 4 blocks) stays padding
             const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            gq[static_cast<uint64_t>(base) * 8u + sub * 2u] = ff;
-            gq[static_cast<uint64_t>(base) * 8u + sub * 2u + 1u] = ff;
+            for (uint32_t b = 0; b < left; ++b) {
+                gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = ff;
+                gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = ff;
+            }
         }
         uint32_t nbase = 0;
         if (need && sub == 0) nbase = atomicAdd(cursor, kRunBlocks);
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
         const bool store = left >= nb;  // false only when the bucket is full
         const uint4* src = &qbuf[wave][q * (kQueueCap / 8)];
 #pragma unroll
-        for (uint32_t b = 0; b < 2; ++b) {
+        for (uint32_t b = 0; b < kQueueBlocks; ++b) {
             if (b < nb) {
                 const uint4 v0 = src[b * 8u + sub * 2u], v1 = src[b * 8u + sub * 2u + 1u];
                 if (store) {
@@ -660,15 +664,16 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
                 }
             }
         }
-        // move the remainder (< one block) to the front: block nb -> block 0 (nb = 1 only;
-        // after two blocks nothing is left because a queue holds two)
+        // move the remainder (< one block) to the front: block nb -> block 0 (after kQueueBlocks
+        // blocks nothing is left)
+        const bool tail = nb != 0u && nb < kQueueBlocks;
         uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
-        if (nb == 1) {
-            k0 = src[8u + sub * 2u];
-            k1 = src[8u + sub * 2u + 1u];
+        if (tail) {
+            k0 = src[nb * 8u + sub * 2u];
+            k1 = src[nb * 8u + sub * 2u + 1u];
         }
         wave_lds_fence();
-        if (nb == 1) {
+        if (tail) {
             qbuf[wave][q * (kQueueCap / 8) + sub * 2u] = k0;
             qbuf[wave][q * (kQueueCap / 8) + sub * 2u + 1u] = k1;
         }
@@ -687,8 +692,8 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
         };
         const uint32_t cnt_base = lds_addr(&qcnt[wave][0]);
-        // data address of queue qq = (counter address << 6) + data_skew, counters being 4 B apart
-        const uint32_t data_skew = lds_addr(&qbuf[wave][0]) - (cnt_base << 6);
+        // data address of queue qq = (counter address << kQueueShift) + data_skew, counters being 4 B apart
+        const uint32_t data_skew = lds_addr(&qbuf[wave][0]) - (cnt_base << kQueueShift);
         // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
         // `bit + 2` = the window ending at p / p + 1 is countable.  A missing partner becomes padding.
         // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             const uint32_t w = (rest_a | (rest_b << 16)) | ~__builtin_amdgcn_perm(keep1, keep0, 0x05040100u);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(at) : : "memory");
             if (at < 2u * kQueueCap) {
-                const uint32_t daddr = (caddr << 6) + data_skew + at;
+                const uint32_t daddr = (caddr << kQueueShift) + data_skew + at;
                 asm volatile("ds_write_b32 %0, %1" : : "v"(daddr), "v"(w) : "memory");
             } else {  // queue full: exact slow path
                 if (keep0) atomicAdd(&hist_s[pair_reverse(x & FMASK, K)], 1u);
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
                         emit_pair(x, ok[g], 4 * j);
                     }
                 }
-                after_group();  // 16 positions of every lane done: drain the queues that hold a block
+                if (g == 3) after_group();  // 64 positions of every lane done: drain the queues that hold a block
             }
         };
         SubWave sw = {0, 0, 0, 0};

@@ -53,6 +53,40 @@ def setup_parser():
                    help="input holds cleaned but UNSPLIT reads (`<int>/clean_reads/<sample>.fq.gz`): draw the "
                         "1-2-5 ladder of subsamples between --min-bp and --max-bp on the GPU (stands in for "
                         "reformat.sh; statistically equivalent, not the same random reads)")
+    q = sub.add_parser("query", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                       help="Query cleaned reads or images against a trained network (cli.py:327-446).")
+    q.add_argument("input", help="folder with cleaned reads (`<sample>.fq[.gz]`, e.g. <int>/clean_reads) or, with "
+                                 "--images, with varKode / rfCGR png files")
+    q.add_argument("outdir", help="path to the folder where results will be saved.")
+    q.add_argument("-R", "--seed", type=int, help="random seed.")
+    q.add_argument("-x", "--overwrite", action="store_true", help="overwrite existing results.")
+    q.add_argument("-v", "--verbose", action="store_true", default=False)
+    q.add_argument("-l", "--model", required=True,
+                   help="local TorchScript archive or pickled torch module (fastai / hub models are not loadable here)")
+    q.add_argument("--vocab", required=True, help="text file, one label per output unit of the model")
+    q.add_argument("--single-label", action="store_true", help="softmax + best label instead of sigmoid >= threshold")
+    q.add_argument("--input-size", type=int, default=224, help="side of the model's input (squish, BOX filter)")
+    q.add_argument("--half", action="store_true", help="run the model under fp16 autocast")
+    q.add_argument("-1", "--no-pairs", action="store_true", help="accepted for parity")
+    q.add_argument("-I", "--images", action="store_true", help="input folder contains processed images instead of reads.")
+    q.add_argument("-k", "--kmer-size", type=int, default=DEFAULT_KMER_SIZE, help="size of kmers to count (5-9)")
+    q.add_argument("-p", "--kmer-mapping", type=str, default=DEFAULT_KMER_MAPPING, choices=MAPPING_CHOICES)
+    q.add_argument("-n", "--n-threads", type=int, default=1, help="host threads for file reading / PNG writing")
+    q.add_argument("-c", "--cpus-per-thread", type=int, default=1, help="accepted for parity, unused")
+    q.add_argument("-f", "--stats-file", default="stats.csv", help="path to file where sample statistics will be saved.")
+    q.add_argument("-d", "--threshold", type=float, default=0.7, help="confidence threshold to make a prediction.")
+    q.add_argument("-i", "--int-folder", help="accepted for parity")
+    q.add_argument("-m", "--keep-images", action="store_true",
+                   help="whether barcode images should be saved to a directory named 'query_images'.")
+    q.add_argument("-P", "--include-probs", action="store_true",
+                   help="whether probabilities for each label should be included in the output.")
+    q.add_argument("-a", "--no-adapter", action="store_true", help="upstream (fastp) option; accepted for parity")
+    q.add_argument("-r", "--no-merge", action="store_true", help="upstream (fastp) option; accepted for parity")
+    q.add_argument("-D", "--no-deduplicate", action="store_true", help="upstream (fastp) option; accepted for parity")
+    q.add_argument("-T", "--trim-bp", default="10,10", help="upstream (fastp) option; accepted for parity")
+    q.add_argument("-M", "--max-bp", default="200M",
+                   help="number of post-cleaning basepairs to use for making image. Use '0' to use all of the available data.")
+    q.add_argument("-b", "--max-batch-size", type=int, default=64, help="maximum batch size for predictions.")
     c = sub.add_parser("convert", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                        help="Convert images between different kmer mappings.")          # cli.py:447-482
     c.add_argument("-R", "--seed", type=int, help="accepted for parity")
@@ -78,6 +112,87 @@ def run_convert(args):
     n = convert_folder(args.input, args.outdir, args.output_mapping, args.input_mapping, args.kmer_size,
                        args.sum_reverse_complements, args.overwrite, max(1, args.n_threads))
     eprint(f"Converted {n} images; written to {args.outdir}")
+
+
+def run_query(args):
+    """`varKoder query` from step C on (commands/query.py:188-324): images are made on the GPU and
+    stay there for the model's input transform; predictions.csv has the reference's columns."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from . import query as Q
+    from .convert import get_metadata_from_img_filename
+    from .engine import ImageEngine
+    from .image import write_png
+    from .subsample import ladder_counts, split_name
+    outdir = Path(args.outdir)
+    if not args.overwrite and (outdir / "predictions.csv").exists():
+        raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
+    model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
+    records, images = [], None
+    if args.images:
+        paths = sorted(Path(args.input).rglob("*.png"))
+        if not paths:
+            raise Exception("No images found to query. Please check your input.")
+        arrays = []
+        for p in paths:
+            im = Image.open(p)
+            md = get_metadata_from_img_filename(p)
+            labels, qual, sd = Q.image_metadata(im.info)
+            records.append(dict(path=str(p), sample=md["sample"], bp=md["bp"], k=md["img_kmer_size"],
+                                mapping=md["img_kmer_mapping"], labels=labels, qual=qual, freq_sd=sd))
+            arrays.append(np.array(im))
+        shapes = {a.shape for a in arrays}
+        if len(shapes) != 1:
+            raise Exception("Images of different sizes in one query are not supported.")
+        eng = ImageEngine(k=records[0]["k"], mapping="cgr")
+        images = torch.from_numpy(np.stack(arrays)).to(eng.device)
+    else:
+        src = Path(args.input)
+        if (src / "clean_reads").is_dir():
+            src = src / "clean_reads"
+        files = sorted(f for f in src.iterdir() if f.is_file() and f.name.endswith((".fq", ".fq.gz", ".fastq", ".fastq.gz")))
+        if not files:
+            raise Exception("No images found to query. Please check your input.")
+        eng = ImageEngine(k=args.kmer_size, mapping=args.kmer_mapping)
+        max_bp = None if str(args.max_bp) == "0" else parse_size(args.max_bp)
+        rng = np.random.default_rng(args.seed)
+        dev, offs, lens = eng.upload_files(files)
+        hists, keep = [], []
+        for i, f in enumerate(files):          # one seed per sample, as image.py:1017
+            sample = str(f.name.removesuffix("".join(f.suffixes)))
+            seed = int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63)
+            rec = ladder_counts(eng, dev, offs[i:i + 1], lens[i:i + 1], seed=seed, max_bp=max_bp, is_query=True)[0]
+            if rec["error"] or not rec["steps"]:
+                eprint("SPLIT FAIL:", f, "-", rec["error"])
+                continue
+            bp, hist, _ = rec["steps"][0]
+            name = split_name(sample, bp) + f"+{args.kmer_mapping}+k{args.kmer_size}.png"
+            path = str(outdir / "query_images" / name) if args.keep_images else name
+            records.append(dict(path=path, sample=sample, bp=int(bp / 1000) * 1000, k=args.kmer_size,
+                                mapping=args.kmer_mapping, labels="", qual=bool("False"), freq_sd=0.0))
+            hists.append(hist)
+            keep.append(name)
+        if not hists:
+            raise Exception("No images found to query. Please check your input.")
+        images = eng.images(torch.stack(hists))
+        if args.keep_images:
+            (outdir / "query_images").mkdir(parents=True, exist_ok=True)
+            host = images.cpu().numpy()
+            for j, name in enumerate(keep):
+                write_png(host[j], outdir / "query_images" / name, [], 0, QUAL_THRESH, args.kmer_mapping)
+    if args.single_label:
+        eprint("This is a single label classification model, each input may will have only one prediction.")
+    else:
+        eprint("This is a multilabel classification model, each input may have 0 or more predictions.")
+    probs = Q.probabilities(eng, images, model, batch_size=args.max_batch_size, multilabel=not args.single_label,
+                            input_size=args.input_size, half=args.half)
+    df = Q.predictions_frame(records, probs, vocab, args.model, args.threshold, not args.single_label,
+                             args.include_probs)
+    outdir.mkdir(parents=True, exist_ok=True)
+    df.to_csv(outdir / "predictions.csv", index=False)
+    eprint("Predictions saved to", str(outdir / "predictions.csv"))
+    eng.close()
 
 
 def read_labels(path):
@@ -202,6 +317,8 @@ def main(argv=None):
         run_image(args)
     elif args.command == "convert":
         run_convert(args)
+    elif args.command == "query":
+        run_query(args)
     eprint("DONE")
 
 

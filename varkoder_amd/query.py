@@ -113,3 +113,83 @@ def predict(engine, images, model, vocab, threshold=0.7, batch_size=64, multilab
         best_p, best_i = torch.max(pp, dim=1)
         labels = [(vocab[i], float(p)) for i, p in zip(best_i.tolist(), best_p.tolist())]
     return pp.numpy(), labels
+
+
+# ---- the `query` command's output (commands/query.py:225-324) ---------------------------------
+
+COMMON_COLUMNS = ("varKode_image_path", "sample_id", "query_basepairs", "query_kmer_len", "query_mapping",
+                  "trained_model_path", "actual_labels", "possible_low_quality", "basefrequency_sd")
+
+
+def image_metadata(info):
+    """(actual_labels, possible_low_quality, basefrequency_sd) from a PNG's text chunks, with the
+    reference's getters' behaviour (core/utils.py:71-107): a missing chunk gives NaN, and the
+    quality flag is `bool(<string>)`, i.e. True for "False" too."""
+    def get(fn):
+        try:
+            return fn()
+        except (AttributeError, TypeError):
+            return np.nan
+    labels = get(lambda: ";".join(x for x in info.get("varkoderKeywords").split(";")))
+    qual = get(lambda: bool(info.get("varkoderLowQualityFlag")))
+    freq_sd = get(lambda: float(info.get("varkoderBaseFreqSd")))
+    return labels, qual, freq_sd
+
+
+def predictions_frame(records, probs, vocab, model_path, threshold=0.7, multilabel=True, include_probs=False):
+    """The reference's predictions.csv as a DataFrame.  records: one dict per image with
+    path, sample, bp, k, mapping, labels, qual, freq_sd; probs float [n, len(vocab)]."""
+    import pandas as pd
+    common = {
+        "varKode_image_path": [r["path"] for r in records],
+        "sample_id": [r["sample"] for r in records],
+        "query_basepairs": [r["bp"] for r in records],
+        "query_kmer_len": [r["k"] for r in records],
+        "query_mapping": [r["mapping"] for r in records],
+        "trained_model_path": str(model_path),
+        "actual_labels": [r["labels"] for r in records],
+        "possible_low_quality": [r["qual"] for r in records],
+        "basefrequency_sd": [r["freq_sd"] for r in records],
+    }
+    probs = np.asarray(probs)
+    if multilabel:
+        predicted = [";".join(vocab[j] for j in np.nonzero(row >= threshold)[0]) for row in probs]
+        df = pd.DataFrame({**common, "prediction_type": "Multilabel", "prediction_threshold": threshold,
+                           "predicted_labels": predicted})
+    else:
+        best = probs.argmax(axis=1)
+        df = pd.DataFrame({**common, "prediction_type": "Single label", "best_pred_label": [vocab[i] for i in best],
+                           "best_pred_prob": probs[np.arange(len(best)), best].tolist()})
+    if include_probs:
+        df = pd.concat([df, pd.DataFrame(probs, columns=list(vocab))], axis=1)
+    return df
+
+
+def load_model(path):
+    """A local TorchScript archive (torch.jit.save) or a pickled torch.nn.Module.  fastai learners
+    and HuggingFace hub names, which the reference also accepts (commands/query.py:150-186), need
+    packages and a network this build does not assume."""
+    import torch
+    try:
+        return torch.jit.load(str(path), map_location="cpu")
+    except RuntimeError:
+        return torch.load(str(path), map_location="cpu", weights_only=False)
+
+
+def read_vocab(path):
+    with open(path) as f:
+        return [ln.rstrip("\n") for ln in f if ln.strip()]
+
+
+def probabilities(engine, images, model, batch_size=64, multilabel=True, input_size=224, half=False):
+    """float32 [n, classes] on the host for uint8 device images [n, side, side]."""
+    import torch
+    model = model.to(images.device).eval()
+    out = []
+    with torch.no_grad():
+        for i in range(0, images.shape[0], batch_size):
+            x = preprocess(engine, images[i:i + batch_size].contiguous(), out_size=input_size)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=half):
+                logits = model(x)
+            out.append((torch.sigmoid(logits) if multilabel else torch.softmax(logits, dim=1)).float().cpu())
+    return torch.cat(out).numpy() if out else np.zeros((0, 0), dtype=np.float32)

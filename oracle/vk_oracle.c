@@ -39,15 +39,11 @@
 #define VKO_EFORMAT 2
 #define VKO_ENOMEM 3
 
-static inline int base_code(uint8_t b) {
-    switch (b) {
-        case 'A': case 'a': return 0;
-        case 'C': case 'c': return 1;
-        case 'G': case 'g': return 2;
-        case 'T': case 't': return 3;
-        default: return -1;
-    }
-}
+/* 0..3 for ACGTacgt, -1 for every other byte (a table: this loop is also the CPU baseline) */
+static const signed char kBaseCode[256] = {
+    ['A'] = 1, ['a'] = 1, ['C'] = 2, ['c'] = 2, ['G'] = 3, ['g'] = 3, ['T'] = 4, ['t'] = 4,
+};
+static inline int base_code(uint8_t b) { return kBaseCode[b] - 1; }
 
 uint32_t vko_revcomp(uint32_t code, int k) {
     uint32_t r = 0;
@@ -73,8 +69,8 @@ int vko_count_fastq(const uint8_t* buf, size_t n, int k, uint32_t* fwd, uint64_t
     unsigned line = 0;
     int status = VKO_OK;
     while (pos < n) {
-        size_t e = pos;
-        while (e < n && buf[e] != '\n') e++;
+        const uint8_t* nl = memchr(buf + pos, '\n', n - pos);
+        size_t e = nl ? (size_t)(nl - buf) : n;
         unsigned ph = line & 3u;
         if (ph == 0) {
             if (buf[pos] != '@') status = VKO_EFORMAT;
@@ -123,8 +119,8 @@ int vko_count_fastq_sampled(const uint8_t* buf, size_t n, int k, uint64_t seed, 
     unsigned line = 0;
     int status = VKO_OK, take = 0;
     while (pos < n) {
-        size_t e = pos;
-        while (e < n && buf[e] != '\n') e++;
+        const uint8_t* nl = memchr(buf + pos, '\n', n - pos);
+        size_t e = nl ? (size_t)(nl - buf) : n;
         unsigned ph = line & 3u;
         if (ph == 0) {
             if (buf[pos] != '@') status = VKO_EFORMAT;

@@ -252,9 +252,15 @@ VKL_FN uint32_t sample_strings_general(const uint32_t NL[4], uint32_t lph, uint6
                                        uint64_t threshold, uint32_t first[4], uint32_t inc[4], uint32_t& last_take) {
     uint32_t cur = lph & 3u, anchors = 0, take = 0;
     last_take = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
     for (int g = 0; g < 4; ++g) {
         uint32_t f = 0, n = 0;
         const uint32_t nl = NL[g];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll  // the rare path: keep it small, its registers would otherwise crowd the piece loop
+#endif
         for (uint32_t b = 0; b < 32; b += 2) {
             if (anchors == 0) f |= 3u << b;
             else if (take) n |= 3u << b;

@@ -116,8 +116,8 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     total += c[lane];
                 }
                 if (it == 0) pph = ph0 - c[0];
-                bool any_gt3 = false;
-                for (int lane = 0; lane < 64; ++lane) any_gt3 |= c[lane] > 3;
+                bool any_gt3 = false, any_eq4 = false;  // the kernel's wave-uniform tiers
+                for (int lane = 0; lane < 64; ++lane) { any_gt3 |= c[lane] > 4; any_eq4 |= c[lane] > 3; }
                 uint32_t excl = 0;
                 if (sub && sub->on && it == 0 && w0 != 0 && (pph & 3u) == 1u) {
                     const uint64_t a = last_newline_before(s, (uint64_t)o0);
@@ -128,7 +128,8 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     excl += c[lane];
                     uint32_t s_raw = 0;
                     vkl::Mask128 seq = any_gt3 ? vkl::seq_mask_general(lb[lane].NL, lph)
-                                               : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
+                                       : any_eq4 ? vkl::seq_mask_fast4(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw)
+                                                 : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
                     uint32_t bad[4], ok[4];
                     vkl::bad_mask(lb[lane], seq, bad);
                     const uint32_t badh = carry_bad, ch = carry_c;  // lane-1's (or last piece's lane 63)
@@ -140,7 +141,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                         // lanes run in order here, so the max-scan of the kernel is a running value
                         const uint64_t base = (uint64_t)(o0 + (long long)it * kPiece) + 64ull * lane;
                         uint32_t first[4], inc[4], anchors, take;
-                        if (any_gt3) {
+                        if (any_gt3 || any_eq4) {
                             anchors = vkl::sample_strings_general(lb[lane].NL, lph, base, sub->seed, sub->threshold,
                                                                   first, inc, take);
                         } else {

@@ -387,9 +387,11 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         const uint32_t lph = (pph + incl - c) & 3u;
 
         vkl::Mask128 seq;
-        const bool degenerate = __any(c > 3u);
+        const bool degenerate = __any(c > 4u);  // wave-uniform tiers: <= 3 newlines per block, 4, more
         uint32_t s_raw = 0;
+        const bool four = !degenerate && __any(c > 3u);
         if (degenerate) seq = vkl::seq_mask_general(lb.NL, lph);
+        else if (four) seq = vkl::seq_mask_fast4(lb.NL, lph, tbl_below, tbl_above, s_raw);
         else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above, s_raw);
         uint32_t bad[4], ok[4];
         vkl::bad_mask(lb, seq, bad);
@@ -414,7 +416,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
                 sub_carry = (a != ~0ull && vkl::sample_take(sw.seed, a, sw.threshold)) ? 1u : 0u;
             }
             uint32_t first[4], inc[4], anchors, take;
-            if (degenerate) {
+            if (degenerate || four) {  // several reads may meet in one block: position by position
                 anchors = vkl::sample_strings_general(lb.NL, lph, base, sw.seed, sw.threshold, first, inc, take);
             } else {
                 anchors = (lph != 1u && s_raw <= 64u) ? 1u : 0u;

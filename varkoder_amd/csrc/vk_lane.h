@@ -227,6 +227,39 @@ VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Ab
     return seq_mask_fast(NL, lph, below, above, s_raw);
 }
 
+// The same with room for a fourth newline (reads shorter than ~45 bases: a 64-byte block can hold
+// the ends of all four lines of a record).  One more newline search and table lookup than
+// seq_mask_fast, so the kernel only takes it when some block of the piece has exactly four.
+// s_raw is as in seq_mask_fast and describes the FIRST interval only.
+template <typename Below, typename Above>
+VKL_FN Mask128 seq_mask_fast4(const uint32_t NL[4], uint32_t lph, Below below, Above above, uint32_t& s_raw) {
+    const uint32_t d = (1u - lph) & 3u;
+    const uint32_t p1 = first_newline(NL);
+    Mask128 m = above(umin(p1 + 1u, 64u));
+    uint32_t r[4] = {NL[0] & m.w[0], NL[1] & m.w[1], NL[2] & m.w[2], NL[3] & m.w[3]};
+    const uint32_t p2 = first_newline(r);
+    m = above(umin(p2 + 1u, 64u));
+    r[0] &= m.w[0]; r[1] &= m.w[1]; r[2] &= m.w[2]; r[3] &= m.w[3];
+    const uint32_t p3 = first_newline(r);
+    m = above(umin(p3 + 1u, 64u));
+    r[0] &= m.w[0]; r[1] &= m.w[1]; r[2] &= m.w[2]; r[3] &= m.w[3];
+    const uint32_t p4 = first_newline(r);
+    // candidates (-1, p1, p2, p3, p4, 64) in consecutive bytes; d = 0..3 picks the pair
+    const uint32_t lo = 0xFFu | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    const uint32_t hi = p4 | (64u << 8);
+    const uint32_t pr = alignbit(hi, lo, 8u * d);
+    const uint32_t s = ((pr & 0xFFu) + 1u) & 0xFFu;
+    const uint32_t e = (pr >> 8) & 0xFFu;
+    s_raw = s;
+    const Mask128 ms = above(umin(s, 64u)), me = below(umin(e, 64u));
+    // A block that starts inside a sequence line (d = 0) and holds four newlines ends inside the
+    // NEXT record's sequence line: a second interval from p4 + 1 on.
+    const Mask128 m2 = above(d == 0u ? umin(p4 + 1u, 64u) : 64u);
+    Mask128 out;
+    for (int g = 0; g < 4; ++g) out.w[g] = (me.w[g] & ms.w[g]) | m2.w[g];
+    return out;
+}
+
 // ---- read subsampling (vk_count_sampled_device) ------------------------------------------------
 // A read is identified by the sample offset of its ANCHOR, the newline that ends its header line,
 // and is counted iff sample_hash(seed, anchor) < threshold (threshold in [0, 2^32]): a pure function

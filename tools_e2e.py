@@ -28,7 +28,7 @@ for threads in (4, 16):
     out = tmp / f"img{threads}"
     t0 = time.perf_counter()
     stats = pipeline.fastqs_to_images(files, out, k=7, mapping_code="varKode", io_threads=threads, engine=eng,
-                                      batch_bytes=4 << 30)
+                                      batch_bytes=1 << 30)
     dt = time.perf_counter() - t0
     assert len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
     res[f"io_threads_{threads}"] = {"files": nfiles, "reads_per_file": reads, "seconds": dt,

@@ -106,9 +106,11 @@ class ImageEngine:
         torch.cuda.current_stream(self.device).synchronize()   # the staging buffer is reused
         return dev, offs, lens
 
-    def upload_files(self, paths, pool=None):
-        """Like upload() for files on disk: plain FASTQ files are read straight into the pinned
-        staging buffer (parallel readinto, no intermediate copy); gzip files are inflated first."""
+    def stage_files(self, paths, pool=None, slot=0):
+        """Host half of upload_files: read the files into pinned staging buffer `slot` (kept and grown
+        across calls).  Plain FASTQ files are read straight into it (parallel readinto, no
+        intermediate copy); gzip files are inflated first.  Touches no GPU state, so a pipeline can
+        stage the next batch on another thread while this one is copied and processed."""
         import gzip
         import os
         torch = _torch()
@@ -130,10 +132,11 @@ class ImageEngine:
             offs[i] = pos
             pos += (int(n) + 15) // 16 * 16
         total = pos + 16
-        pinned = getattr(self, "_pinned", None)
+        slots = self.__dict__.setdefault("_pinned_slots", {})
+        pinned = slots.get(slot)
         if pinned is None or pinned.numel() < total:
             pinned = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            self._pinned = pinned
+            slots[slot] = pinned
         host = pinned.numpy()
 
         def fill(i):
@@ -148,10 +151,21 @@ class ImageEngine:
             host[o + n:(o + n + 15) // 16 * 16] = 0
         list(mapper(fill, range(len(paths))))
         host[pos:total] = 0
+        return pinned, total, offs, lens
+
+    def upload_staged(self, staged):
+        """Device half: one H2D DMA of a staged batch; returns (tensor, offsets, lengths).  The
+        staging buffer may be refilled once this returns."""
+        torch = _torch()
+        pinned, total, offs, lens = staged
         dev = torch.empty(total, dtype=torch.uint8, device=self.device)
         dev.copy_(pinned[:total], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return dev, offs, lens
+
+    def upload_files(self, paths, pool=None):
+        """Like upload() for files on disk (stage_files + upload_staged)."""
+        return self.upload_staged(self.stage_files(paths, pool))
 
     # -- stages ----------------------------------------------------------------
     def count(self, fastq, offsets, lengths, parts=0, hist=None, status=None):

@@ -53,19 +53,27 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         todo.append(f)
 
     import os
-    i = 0
-    while i < len(todo):
-        # batch by on-disk size (gzip files count 4x: they are inflated on the host first)
-        batch, nbytes = [], 0
+    # batches by on-disk size (gzip files count 4x: they are inflated on the host first)
+    batches, batch, nbytes = [], [], 0
+    for f in todo:
+        sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
+        if batch and nbytes + sz > batch_bytes:
+            batches.append((batch, nbytes))
+            batch, nbytes = [], 0
+        batch.append(f)
+        nbytes += sz
+    if batch:
+        batches.append((batch, nbytes))
+    # The host half of a batch (file reads into a pinned buffer) runs one batch ahead on its own
+    # thread, into the other of two staging buffers, while this thread copies and processes.
+    stager = ThreadPoolExecutor(1)
+    staged = stager.submit(eng.stage_files, batches[0][0], pool, 0) if batches else None
+    for bi, (batch, nbytes) in enumerate(batches):
         t0 = time.perf_counter()
-        for f in todo[i:]:
-            sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
-            if batch and nbytes + sz > batch_bytes:
-                break
-            batch.append(f)
-            nbytes += sz
-        i += len(batch)
-        dev, offs, lens = eng.upload_files(batch, pool)
+        ready = staged.result()
+        if bi + 1 < len(batches):
+            staged = stager.submit(eng.stage_files, batches[bi + 1][0], pool, (bi + 1) & 1)
+        dev, offs, lens = eng.upload_staged(ready)
         t1 = time.perf_counter()
         img, hist, status = eng.fastq_to_images(dev, offs, lens)
         st = status.cpu().numpy()
@@ -89,6 +97,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
                                         QUAL_THRESH, mapping_code)))
         if verbose:
             eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
+    stager.shutdown()
     for key, t, fut in pending:
         fut.result()
         stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t

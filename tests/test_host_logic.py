@@ -112,3 +112,65 @@ def test_dsk_text_dump_roundtrip():
     t = formats.dsk_text(np.eye(1, 4 ** 5, mapping.codes_of(["GGGGA"])[0], dtype=np.uint32)[0], 5, "gatb")
     assert t in ("GGGGA 1\n", "TCCCC 1\n") and t == "TCCCC 1\n"      # T < G in GATB's order
     assert formats.dsk_text(np.eye(1, 4 ** 5, mapping.codes_of(["GGGGA"])[0], dtype=np.uint32)[0], 5, "lex") == "GGGGA 1\n"
+
+
+def test_file_pipeline_batches_and_overlaps_without_a_gpu(tmp_path):
+    """pipeline.fastqs_to_images with a stand-in engine (the oracle does the arithmetic): batching
+    by size, staging of the next batch on another thread, file naming, stats keys, PNG contents."""
+    import threading
+
+    import torch
+    from PIL import Image
+    from oracle import oracle
+    from varkoder_amd import pipeline, synth
+    from varkoder_amd.mapping import pixel_lut
+
+    lut = pixel_lut(5, "cgr")
+    log = []
+
+    class FakeEngine:
+        def stage_files(self, paths, pool=None, slot=0):
+            log.append(("stage", slot, [p.name for p in paths], threading.current_thread().name))
+            blobs = [p.read_bytes() for p in paths]
+            return blobs, slot
+
+        def upload_staged(self, staged):
+            blobs, slot = staged
+            log.append(("upload", slot))
+            lens = np.array([len(b) for b in blobs], dtype=np.uint64)
+            return blobs, np.zeros(len(blobs), dtype=np.uint64), lens
+
+        def fastq_to_images(self, dev, offs, lens):
+            imgs, hists, sts = [], [], []
+            for b in dev:
+                fwd, _, st = oracle.count_fastq(b, 5)
+                imgs.append(oracle.image(oracle.strand_merge(fwd, 5), 5, lut, 1024).reshape(32, 32))
+                hists.append(fwd.astype(np.int32))
+                sts.append(st)
+            return (torch.from_numpy(np.stack(imgs)), torch.from_numpy(np.stack(hists)),
+                    torch.from_numpy(np.array(sts, dtype=np.int32)))
+
+        def close(self):
+            pass
+
+    files = []
+    for i in range(7):
+        f = tmp_path / f"s{i}@00000030K.fq"
+        f.write_bytes(synth.sample_fastq(i, 200, 150).tobytes())
+        files.append(f)
+    (tmp_path / "bad@00000001K.fq").write_bytes(b"@r\nACGTACGTAC\n+\nIIIIIIIIII\n@r2\nACGT\n")
+    files.append(tmp_path / "bad@00000001K.fq")
+    size = files[0].stat().st_size
+    stats = pipeline.fastqs_to_images(files, tmp_path / "out", k=5, mapping_code="cgr", batch_bytes=3 * size + 10,
+                                      io_threads=2, engine=FakeEngine())
+    stages = [e for e in log if e[0] == "stage"]
+    assert [len(e[2]) for e in stages] == [3, 3, 2] and [e[1] for e in stages] == [0, 1, 0]
+    assert all(e[3] != threading.current_thread().name for e in stages)          # staged off the main thread
+    assert [e[1] for e in log if e[0] == "upload"] == [0, 1, 0]
+    assert stats["bad@00000001K"]["failed_step"] == "image"
+    for i in range(7):
+        st = stats[f"s{i}@00000030K"]
+        assert "5mer_counting_time" in st and "k5_img_time" in st
+        want = oracle.fastq_to_image(synth.sample_fastq(i, 200, 150), 5, lut, 1024)[0].reshape(32, 32)
+        im = Image.open(tmp_path / "out" / f"s{i}@00000030K+cgr+k5.png")
+        assert np.array_equal(np.array(im), want) and im.info["varkoderMapping"] == "cgr"

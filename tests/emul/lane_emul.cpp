@@ -129,7 +129,8 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     uint32_t s_raw = 0;
                     vkl::Mask128 seq = any_gt3 ? vkl::seq_mask_general(lb[lane].NL, lph)
                                        : any_eq4 ? vkl::seq_mask_fast4(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw)
-                                                 : vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
+                                       : (sub && sub->on) ? vkl::seq_mask_fast(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw)
+                                                          : vkl::seq_mask_count(lb[lane].NL, lph);
                     uint32_t bad[4], ok[4];
                     vkl::bad_mask(lb[lane], seq, bad);
                     const uint32_t badh = carry_bad, ch = carry_c;  // lane-1's (or last piece's lane 63)

@@ -14,10 +14,10 @@ from varkoder_amd import _capi
 if sys.argv[1] != "default":
     _capi.LIB_PATH = sys.argv[1]
 from varkoder_amd.engine import ImageEngine
-k = int(sys.argv[2]); samples = int(sys.argv[3]); dist = int(sys.argv[4])
+k = int(sys.argv[2]); samples = int(sys.argv[3]); dist = int(sys.argv[4]); pool = int(sys.argv[5])
 eng = ImageEngine(k=k, mapping="cgr")
-fq, po, pl = eng.synth(0, 64, 1_000_000, 150, dist=dist)
-idx = np.arange(samples) % 64
+fq, po, pl = eng.synth(0, pool, 1_000_000, 150, dist=dist)
+idx = np.arange(samples) % pool
 offs, lens = po[idx].copy(), pl[idx].copy()
 hist = torch.empty((samples, 4 ** k), dtype=torch.int32, device="cuda")
 status = torch.empty((samples,), dtype=torch.int32, device="cuda")
@@ -27,7 +27,7 @@ for _ in range(3):
     t0 = time.perf_counter(); eng.count(fq, offs, lens, hist=hist, status=status); torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 h = hashlib.sha256(hist[:64].cpu().numpy().tobytes()).hexdigest()[:16]
-print(f"{sys.argv[1]:40s} k={k} dist={dist} K1 {min(ts)*1e3:8.2f} ms (min of 3; {[round(t*1e3,1) for t in ts]}) bad={int((status!=0).sum())} sha={h}", flush=True)
+print(f"{sys.argv[1]:40s} k={k} dist={dist} pool={pool} K1 {min(ts)*1e3:8.2f} ms (min of 3; {[round(t*1e3,1) for t in ts]}) bad={int((status!=0).sum())} sha={h}", flush=True)
 """
 
 if __name__ == "__main__":
@@ -35,12 +35,14 @@ if __name__ == "__main__":
     k = 7
     samples = 1000
     dist = 0
+    pool = 64
     for a in sys.argv[1:]:
         if a.startswith("--k="): k = int(a[4:])
         if a.startswith("--samples="): samples = int(a[10:])
         if a.startswith("--dist="): dist = int(a[7:])
+        if a.startswith("--pool="): pool = int(a[7:])
     rc = 0
     for lib in ["default"] + libs:
-        r = subprocess.run([sys.executable, "-c", CHILD, lib, str(k), str(samples), str(dist)])
+        r = subprocess.run([sys.executable, "-c", CHILD, lib, str(k), str(samples), str(dist), str(pool)])
         rc |= r.returncode
     sys.exit(rc)

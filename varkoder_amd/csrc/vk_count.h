@@ -15,6 +15,12 @@ constexpr int kWaves = 16;             // wavefronts per count workgroup
 constexpr int kCountThreads = kWaves * 64;
 constexpr int kPiece = 4096;           // bytes per wave iteration (64 lanes x 64 B)
 constexpr uint32_t kMaxBins = 16384;   // u32 LDS histogram bins per workgroup (64 KiB)
+#ifndef VK_K1_OCC
+#define VK_K1_OCC 8                     // waves per SIMD the LDS-histogram kernel is compiled for (two workgroups per CU)
+#endif
+#ifndef VK_K1_PF
+#define VK_K1_PF 2                      // when the next piece is loaded: 0 at its own start, 1 after classify, 2 before the windows (fewest registers held longest)
+#endif
 
 // ---------------------------------------------------------------- helpers ----
 
@@ -313,42 +319,73 @@ __device__ unsigned long long g_vk_stamps[8];
     } while (0)
 #endif
 
-template <int K, bool SUB, typename Windows>
-__device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, uint64_t len, uint64_t w0,
-                                            uint64_t w1, uint64_t* scratch, const uint4* below, const uint4* above,
+// A value every lane of the wavefront holds alike, moved to scalar registers (the compiler cannot
+// prove uniformity of anything derived from threadIdx or from a select).
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+template <int K, bool SUB, int PF, typename Windows>
+__device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, uint64_t len_, uint64_t w0_,
+                                            uint64_t w1_, uint64_t* scratch, const uint4* below, const uint4* above,
                                             int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end,
                                             SubWave& sw) {
+    // the range is the same for the whole wave: keep it (and everything derived from it: piece
+    // addresses, loop counter, edge tests) in scalar registers
+    const uint8_t* sbase = reinterpret_cast<const uint8_t*>(uniform64(reinterpret_cast<uint64_t>(sbase_)));
+    const uint64_t len = uniform64(len_), w0 = uniform64(w0_), w1 = uniform64(w1_);
     const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, scratch, lane) : 0u;
     ph_start = ph0;
 
     // Pieces start one 64-byte block BEFORE the range: lane 0 of piece 0 (the "pre-block")
     // only supplies the k-1 bases of context and its windows are not counted.  From then on
-    // lane 0 takes its context from lane 63 of the previous piece.
-    const long long o0 = static_cast<long long>(w0) - 64;
-    const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
-    uint4 r0, r1, r2, r3;
+    // lane 0 takes its context from lane 63 of the previous piece.  A range that starts at
+    // offset 0 has no bytes before it and no pre-block.
+    const bool has_pre = w0 != 0;
+    const uint64_t o0 = has_pre ? w0 - 64 : 0;                                // sample offset of piece 0
+    const uint64_t span = w1 - o0;                                            // bytes from there to w1
+    const uint32_t npieces = static_cast<uint32_t>((span + kPiece - 1) / kPiece);
+    const uint32_t tail_bytes = static_cast<uint32_t>(span % kPiece);         // bytes of a last, partial piece
+    const uint32_t lane64 = static_cast<uint32_t>(lane) * 64u;
     // Every lane loads ITS 64 contiguous bytes (four 16-byte loads): one instruction touches 64
     // cache lines, but the four together use them completely and the lines stay in the CU's L1
     // between them -- measured HBM traffic equals the file size, and the former LDS transpose
     // (coalesced rows in, lane blocks out: 8 LDS instructions and 64 KiB of LDS) bought nothing.
-    // A piece wholly inside [0, w1) is loaded unguarded; edge pieces zero-fill.
-    auto load_piece = [&](uint64_t piece) {
-        const long long pb = o0 + static_cast<long long>(piece) * kPiece;
-        if (pb >= 0 && static_cast<uint64_t>(pb) + kPiece <= w1) {  // wave-uniform
-            const uint4* g = reinterpret_cast<const uint4*>(sbase + pb) + 4 * lane;
-            r0 = g[0];
-            r1 = g[1];
-            r2 = g[2];
-            r3 = g[3];
-        } else {
-            const long long p = pb + static_cast<long long>(lane) * 64;
-            r0 = load_granule_s(sbase, p, w1);
-            r1 = load_granule_s(sbase, p + 16, w1);
-            r2 = load_granule_s(sbase, p + 32, w1);
-            r3 = load_granule_s(sbase, p + 48, w1);
-        }
+    // The loads go through a buffer descriptor over [o0, w1 rounded up to 16): granules at or beyond
+    // that end come back as zeros from the hardware's range check, so every piece -- the last, partial
+    // one included -- takes the same four instructions (scalar piece offset + the lane's 32-bit
+    // offset, no 64-bit address registers, no edge branch).  w1 is a multiple of 64 unless it is the
+    // end of the sample, whose last granule the ABI makes readable; its bytes at and beyond w1 are
+    // cleared below (it == npieces - 1).  (vkimg.hip keeps a wave's range below 4 GiB.)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(sbase + o0), 0, static_cast<int>((span + 15) & ~15ull), 0x00020000);
+    uint4 r0, r1, r2, r3;
+    auto load_piece = [&](uint32_t piece) {
+        const uint32_t soff = piece * static_cast<uint32_t>(kPiece);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64, soff, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64 + 16u, soff, 0);
+        const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64 + 32u, soff, 0);
+        const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64 + 48u, soff, 0);
+        r0 = make_uint4(a.x, a.y, a.z, a.w);
+        r1 = make_uint4(b.x, b.y, b.z, b.w);
+        r2 = make_uint4(c.x, c.y, c.z, c.w);
+        r3 = make_uint4(d.x, d.y, d.z, d.w);
     };
-    load_piece(0);
+    // the one granule that can hold bytes at or beyond w1 (see above): keep its first n bytes
+    auto clip_granule = [](uint4& v, int n) {
+        if (n >= 16) return;
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int kb = n - 4 * d;
+            w[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    if (PF != 0) load_piece(0);
     uint32_t carry_c = 0u, carry_bad = 0x55555555u;
     uint32_t pph = 0;  // line phase at the start of the current piece
     uint32_t sub_carry = 0u;  // SUB: is the read that runs into the current piece taken?
@@ -367,8 +404,18 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
 #ifdef VK_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc[4] = {0, 0, 0, 0};
 #endif
-    for (uint64_t it = 0; it < npieces; ++it) {
+    for (uint32_t it = 0; it < npieces; ++it) {
         VK_STAMP(t0);
+        if (PF == 0) load_piece(it);
+        if (it + 1 == npieces && (tail_bytes & 15u) != 0u) {  // wave-uniform, once per range at most
+            uint32_t tb = tail_bytes;
+            asm volatile("" : "+s"(tb));  // keeps the masks of this cold path from being hoisted into registers held across the loop
+            const int n = static_cast<int>(tb) - static_cast<int>(lane64);
+            clip_granule(r0, n);
+            clip_granule(r1, n - 16);
+            clip_granule(r2, n - 32);
+            clip_granule(r3, n - 48);
+        }
         const uint4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;  // this lane's 64 bytes
         const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -378,12 +425,12 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
 
         // prefetch the next piece under the rest of the work; the bytes of this one are consumed, so
         // the loads land in the same registers
-        if (it + 1 < npieces) load_piece(it + 1);
+        if (PF == 1 && it + 1 < npieces) load_piece(it + 1);
         VK_STAMP(t2);
         // newline prefix over the wave -> line phase at the start of each lane's block
         const uint32_t incl = wave_inclusive_sum(c);
         const uint32_t total = lane_bcast(incl, 63);
-        if (it == 0) pph = ph0 - lane_bcast(c, 0);  // the pre-block's newlines precede w0
+        if (it == 0) pph = has_pre ? ph0 - lane_bcast(c, 0) : 0u;  // the pre-block's newlines precede w0
         const uint32_t lph = (pph + incl - c) & 3u;
 
         vkl::Mask128 seq;
@@ -392,7 +439,8 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         const bool four = !degenerate && __any(c > 3u);
         if (degenerate) seq = vkl::seq_mask_general(lb.NL, lph);
         else if (four) seq = vkl::seq_mask_fast4(lb.NL, lph, tbl_below, tbl_above, s_raw);
-        else seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above, s_raw);
+        else if constexpr (SUB) seq = vkl::seq_mask_fast(lb.NL, lph, tbl_below, tbl_above, s_raw);  // needs s_raw
+        else seq = vkl::seq_mask_count(lb.NL, lph);  // no LDS lookups in the steady state
         uint32_t bad[4], ok[4];
         vkl::bad_mask(lb, seq, bad);
 
@@ -402,17 +450,17 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
         carry_c = lane_bcast(lb.C[3], 63);
 
         vkl::ok_mask<K>(badh, bad, ok);
-        if (it == 0 && lane == 0) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+        if (it == 0 && lane == 0 && has_pre) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
 
         if constexpr (SUB) {
             // Which read does each position belong to, and is that read taken?  A block either has
             // an anchor (the newline that ends a header line) and decides for what follows it, or
             // inherits the decision of the nearest anchor before it: a max-scan over
             // (lane + 1) << 1 | take, seeded with the decision carried in from the previous piece.
-            const uint64_t base = static_cast<uint64_t>(o0 + static_cast<long long>(it) * kPiece) + 64ull * lane;
+            const uint64_t base = o0 + static_cast<uint64_t>(it) * kPiece + 64ull * lane;
             if (it == 0 && w0 != 0 && (pph & 3u) == 1u) {
                 // the range is entered inside a sequence line whose header ended before the pre-block
-                const uint64_t a = last_newline_before(sbase, static_cast<uint64_t>(o0), lane);
+                const uint64_t a = last_newline_before(sbase, o0, lane);
                 sub_carry = (a != ~0ull && vkl::sample_take(sw.seed, a, sw.threshold)) ? 1u : 0u;
             }
             uint32_t first[4], inc[4], anchors, take;
@@ -431,7 +479,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
             sub_carry = max(lane_bcast(scan, 63), sub_carry) & 1u;
             const uint32_t inh = 0u - inherited;
             // the pre-block belongs to the previous range; bytes at or beyond w1 are zero fill
-            const bool mine = !(it == 0 && lane == 0) && base < w1;
+            const bool mine = !(it == 0 && lane == 0 && has_pre) && base < w1;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint32_t takem = (first[g] & inh) | inc[g];
@@ -444,6 +492,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase, u
             }
         }
         VK_STAMP(t3);
+        if (PF == 2 && it + 1 < npieces) load_piece(it + 1);
         windows(ch, lb.C, ok);  // the consumer's window stage (LDS histogram or bucket queues)
         pph += total;
 #ifdef VK_STAMPS
@@ -481,7 +530,7 @@ __device__ __forceinline__ void flush_sites(const SubParams& sp, uint32_t s, con
 }
 
 template <int K, bool SUB>
-__global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
+__global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush, SubParams sp) {
@@ -500,7 +549,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
     const uint32_t part = unit % parts;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the range and the piece loop live on the SALU
 
     for (uint32_t i = tid; i < NCODE; i += kCountThreads) hist[i] = 0u;
     fill_mask_tables(below, above, tid);
@@ -521,7 +570,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_count_kernel(
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB, SUB ? 1 : VK_K1_PF>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
     }
@@ -758,7 +807,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB, 1>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
         // final drain: pad the last partial block of every queue, write it, then the rest of every run
         wave_lds_fence();

@@ -227,6 +227,43 @@ VKL_FN Mask128 seq_mask_fast(const uint32_t NL[4], uint32_t lph, Below below, Ab
     return seq_mask_fast(NL, lph, below, above, s_raw);
 }
 
+// The same mask by COUNTING instead of searching (at most three newlines in the block): position p
+// is in a sequence line iff the number of newlines at positions <= p equals d, the number of line
+// ends still to pass at the block start.  The 2-bit slot of every position holds that count: four
+// shift-adds per dword give the prefix sums inside a dword (a total of at most three never carries
+// out of a slot), the newlines of the dwords before are added replicated into every slot, and one
+// xor against d replicated leaves a zero slot exactly where the counts agree.  Pure VALU work with
+// four independent dword chains -- no table lookups, so the piece loop never waits for LDS behind
+// its own histogram atomics.  (A newline's own slot already counts it: the newline that ends a
+// header line is marked, but it is not a base and BAD takes it out; callers that need sites
+// mask with ~NL.)  Result on the even bits only.
+VKL_FN uint32_t rep_slots(uint32_t v) {  // v = 0..3 replicated into all sixteen 2-bit slots
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t r = __umul24(v, 0x555555u);
+    return r | (r << 8);
+#else
+    return v * 0x55555555u;
+#endif
+}
+
+VKL_FN Mask128 seq_mask_count(const uint32_t NL[4], uint32_t lph) {
+    const uint32_t want = rep_slots((1u - lph) & 3u);
+    Mask128 out;
+    uint32_t before = 0;  // newlines in the dwords before this one
+    for (int g = 0; g < 4; ++g) {
+        uint32_t x = NL[g];
+        x += x << 2;
+        x += x << 4;
+        x += x << 8;
+        x += x << 16;
+        if (g) x += rep_slots(before);
+        before += popc(NL[g]);
+        const uint32_t z = x ^ want;
+        out.w[g] = ~(z | (z >> 1)) & 0x55555555u;
+    }
+    return out;
+}
+
 // The same with room for a fourth newline (reads shorter than ~45 bases: a 64-byte block can hold
 // the ends of all four lines of a record).  One more newline search and table lookup than
 // seq_mask_fast, so the kernel only takes it when some block of the piece has exactly four.
@@ -325,6 +362,9 @@ VKL_FN Mask128 seq_mask_general(const uint32_t NL[4], uint32_t lph) {
     for (int g = 0; g < 4; ++g) {
         uint32_t acc = 0;
         const uint32_t nl = NL[g];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll  // the rare path: unrolled, its sixteen shifted constants would sit in registers across the piece loop
+#endif
         for (uint32_t b = 0; b < 32; b += 2) {
             acc |= (cur == 1u ? 3u : 0u) << b;
             cur = (cur + ((nl >> b) & 1u)) & 3u;

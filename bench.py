@@ -11,9 +11,12 @@ of `--pool` distinct samples (default 256 = 82 GB, one per concurrently resident
 batch of 1000 cycles through it; every batch entry still gets its own histogram and
 image.  Generation is outside the timed region.
 
-N>1: one process per GPU (torchrun), samples shard across ranks with no data-path
-collective (weak scaling: every rank runs the same per-GPU batch on its own pool);
-the only collective is the MAX-reduce of the elapsed time.
+N>1 = BASELINE.json configs[2]: 10000 samples sharded over the N GPUs (ceil(10000/N) per rank per
+step, no data-path collective: samples are independent, as in the reference's sample-level pool,
+varKoder/commands/image.py:1281-1284); every rank keeps its own pool of distinct samples.  The only
+collectives are the barrier and the MAX-reduce of the elapsed time.  `--gpus N` without a launcher
+(no WORLD_SIZE in the environment) starts the N ranks itself, as fresh child processes, before
+anything in this process touches the GPU; under torchrun (the driver's way) it must equal WORLD_SIZE.
 
 Prints ONE JSON line on rank 0.
 """
@@ -36,7 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=1000, help="samples per GPU per step")
+    ap.add_argument("--samples", type=int, default=0, help="samples per GPU per step (default: 1000 at N=1 = "
+                    "configs[1]; ceil(total/N) at N>1 = configs[2])")
+    ap.add_argument("--total-samples", type=int, default=10000, help="samples per step over all ranks at N>1")
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--readlen", type=int, default=150)
     ap.add_argument("--k", type=int, default=7)
@@ -46,15 +51,65 @@ def parse():
     ap.add_argument("--parts", type=int, default=0, help="workgroups per sample (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this "
+                    "process may use: physical cores, capped by affinity and the cgroup's CPU quota)")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N>1 (nccl = RCCL); "
                     "gloo allows a 2-rank rehearsal on a single GPU together with --all-on-device0")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
+def cpu_budget():
+    """Cores this process can really use: physical cores of the host (unique physical id / core id
+    pairs in /proc/cpuinfo), capped by the scheduler affinity and by the cgroup's CPU quota."""
+    host = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    physical = len(phys) or host
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = host
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                tok = f.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    quota = float(tok[0]) / float(tok[1])
+            else:
+                q = float(tok[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        quota = q / float(g.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = min(physical, affinity)
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return {"host_cpus": host, "physical_cores": physical, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+            "usable_cores": usable}
+
+
 def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     """The oracle's C restatement ("port") timed on this host's cores on a bounded sample
-    of the same workload: whole samples of the device-generated pool, copied back."""
+    of the same workload: whole samples of the device-generated pool, copied back.  Runs on every
+    core this process may use (cpu_budget) and, for the record, on one thread."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     from varkoder_amd.mapping import pixel_lut, side
@@ -64,7 +119,8 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     nbuf = min(4, len(offs))
     bufs = [fastq_dev[int(offs[i]):int(offs[i]) + int(lens[i])].cpu().numpy() for i in range(nbuf)]
     bases_per_sample = args.reads * args.readlen
-    cores = min(os.cpu_count() or 1, 16)
+    budget = cpu_budget()
+    cores = args.cpu_threads if args.cpu_threads > 0 else budget["usable_cores"]
 
     def one(i):
         img, nwin, st = oracle.fastq_to_image(bufs[i % nbuf], args.k, lut, n * n)
@@ -83,9 +139,10 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     dt = time.perf_counter() - t0
     out = {"value": nsamp * bases_per_sample / dt / 1e9, "unit": "Gbases/s", "cores": cores,
            "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9, "cpu_model": cpu_model(),
-           "host_cpus": os.cpu_count(),
+           "speedup_over_one_thread": (nsamp * bases_per_sample / dt) / (bases_per_sample / t1),
            "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
                      f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
+    out.update(budget)
     ref = dsk_reference(bufs[0], args, cores)
     if ref:
         out["dsk"] = ref
@@ -139,12 +196,44 @@ def dsk_reference(buf, args, cores):
         return res
 
 
+def spawn_ranks(args):
+    """`--gpus N` with no launcher: start N fresh child processes (one rank per GPU) BEFORE this
+    process has imported torch or touched the GPU, relay rank 0's JSON line, return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                         f"--nproc-per-node {args.gpus} or drop the launcher\n")
+        sys.exit(2)
+    if args.samples <= 0:
+        args.samples = 1000 if world == 1 else -(-args.total_samples // world)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.all_on_device0:
@@ -216,24 +305,34 @@ def main():
         # FASTQ text read once + the 4^k u32 histogram written once, per sample
         alg_bytes = args.samples * (fastq_bytes + 4 * ncode)
         achieved = alg_bytes / (count_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes (profiles/): only quoted when
+        # that profile was taken on this kernel and this configuration, otherwise null
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    tj = json.load(f)
+                want = {"k": args.k, "samples": args.samples, "reads": args.reads, "readlen": args.readlen,
+                        "pool": pool, "dist": args.dist}
+                if tj.get("config") == want:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
             "metric": "Gbases/s for `varKoder image` k=%d, %d bp reads" % (args.k, args.readlen),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "samples_per_s": args.samples * world * args.steps / elapsed,
-            "config": {"workload": "%d synthetic samples x %d x %d bp reads per GPU, k=%d %s (%dx%d), "
-                                   "FASTQ text resident in HBM" % (args.samples, args.reads, args.readlen,
-                                                                   args.k, args.mapping, eng.side, eng.side),
+            "config": {"workload": "%s: %d synthetic samples x %d x %d bp reads per GPU per step, k=%d %s (%dx%d), "
+                                   "FASTQ text resident in HBM" % (
+                                       "BASELINE configs[1]" if world == 1 else
+                                       "BASELINE configs[2] (%d samples sharded over %d GPUs)" % (args.samples * world, world),
+                                       args.samples, args.reads, args.readlen, args.k, args.mapping, eng.side, eng.side),
+                       "process_group": {"backend": dist.get_backend() if world > 1 else None,
+                                         "world_size": dist.get_world_size() if world > 1 else 1},
                        "samples_per_gpu": args.samples, "reads_per_sample": args.reads,
                        "read_len": args.readlen, "k": args.k, "mapping": args.mapping,
                        "distinct_samples_in_hbm": pool, "base_distribution": args.dist,

@@ -41,7 +41,15 @@ ck = next((k for k in pmc if k.startswith("vk_count_kernel")), None)
 if ck and "FETCH_SIZE" in pmc[ck] and "WRITE_SIZE" in pmc[ck]:
     fetch = pmc[ck]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2   # KB -> B, gfx950 x2
     write = pmc[ck]["WRITE_SIZE"]["mean_per_dispatch"] * 1024
-    t = {"kernel": ck, "tag": tag, "fetch_bytes_corrected": fetch, "write_bytes": write,
+    cfg = None  # the configuration the counter passes ran (bench.py quotes the traffic only for the same one)
+    try:
+        line = [l for l in open(os.path.join(src, "bench_fetch.json")) if l.startswith("{")][-1]
+        c = json.loads(line)["config"]
+        cfg = {"k": c["k"], "samples": c["samples_per_gpu"], "reads": c["reads_per_sample"], "readlen": c["read_len"],
+               "pool": c["distinct_samples_in_hbm"], "dist": c["base_distribution"]}
+    except Exception:
+        pass
+    t = {"kernel": ck, "tag": tag, "config": cfg, "fetch_bytes_corrected": fetch, "write_bytes": write,
          "hbm_bytes_per_launch": fetch + write,
          "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024, separate --pmc passes, 1000-sample launch"}
     json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)

@@ -212,6 +212,30 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert "workload" in d["config"]
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`bench.py --gpus 2` with no launcher: the script starts its two ranks (both on cuda:0 here,
+    gloo for the control plane) and the line it prints says so; each rank runs half of the batch."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--all-on-device0",
+                          "--backend", "gloo", "--steps", "2", "--warmup", "1", "--total-samples", "24", "--pool", "6",
+                          "--reads", "20000"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["bad_status_samples"] == 0
+    assert d["config"]["samples_per_gpu"] == 12
+    assert d["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
+    assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d
+    # a launcher that disagrees with --gpus is an error, not a silent one-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """examples/fastq_to_pgm.c: the shared library used from C without Python or PyTorch in the
     process; its image equals the oracle's."""

@@ -134,3 +134,52 @@ def test_giant_sample_split_and_allreduce_is_exact():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert st == 0 and np.array_equal(total, want)
+
+
+def test_u32_counts_widen_unsigned():
+    """A per-rank count of 2^31 or more must not turn negative on the way into the 64-bit all-reduce."""
+    import torch
+    from varkoder_amd import shard
+    raw = np.array([0x80000001, 0xFFFFFFFF, 5, 0], dtype=np.uint32)
+    t = torch.from_numpy(raw.view(np.int32).copy())
+    assert t[0].item() < 0                                   # what a plain .to(int64) would sign-extend
+    w = shard.widen_u32(t)
+    assert w.dtype == torch.int64 and w.tolist() == [0x80000001, 0xFFFFFFFF, 5, 0]
+
+
+def _giant_gpu_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from varkoder_amd import synth
+    from varkoder_amd.engine import ImageEngine, count_giant_sample
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = ImageEngine(k=7, mapping="cgr", device=0)           # both ranks on cuda:0: a rehearsal of the data path
+    fq = synth.sample_fastq(77, 30000, 150, dist=1)
+    h, st = count_giant_sample(eng, fq, rank=rank, world=world)
+    if rank == 0:
+        out.put((st, h.cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_giant_sample_over_two_ranks_through_the_kernel():
+    """engine.count_giant_sample at world = 2 with the HIP count kernel doing each rank's range
+    (both ranks on the one GPU of the test box, gloo as the process group)."""
+    from oracle import oracle
+    from varkoder_amd import synth
+    fq = synth.sample_fastq(77, 30000, 150, dist=1)
+    want = oracle.count_fastq(fq, 7)[0].astype(np.int64)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_giant_gpu_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    st, total = out.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert st == 0 and np.array_equal(total, want)

@@ -2,7 +2,8 @@
 // function of waves per SIMD.  Every kernel is a loop of 32 instructions of ONE kind
 // (eight independent accumulators x four rounds) written in inline asm so hipcc cannot fold or re-select them;
 // cycles are read inside the kernel with s_memtime (shader clock), so no clock is assumed.
-// Reported: cycles per instruction per SIMD = wave cycles / (instructions per wave x waves per SIMD).
+// (Rows named a_then_b hold two or four instructions per slot: divide by that.)
+// Reported: s_memtime ticks per instruction per SIMD = wave cycles / (instructions per wave x waves per SIMD).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/issue_rate.hip -o tools/issue_rate.bin
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -229,6 +230,151 @@ struct v_and_then_s_nop {
     }
 };
 
+struct v_and_b32_sgpr {
+    static constexpr const char* name = "v_and_b32_sgpr";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_and_b32 " "%0" ", %9, " "%0" "\n\t" "v_and_b32 " "%1" ", %9, " "%1" "\n\t" "v_and_b32 " "%2" ", %9, " "%2" "\n\t" "v_and_b32 " "%3" ", %9, " "%3" "\n\t" "v_and_b32 " "%4" ", %9, " "%4" "\n\t" "v_and_b32 " "%5" ", %9, " "%5" "\n\t" "v_and_b32 " "%6" ", %9, " "%6" "\n\t" "v_and_b32 " "%7" ", %9, " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_and_b32_literal {
+    static constexpr const char* name = "v_and_b32_literal";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_and_b32 " "%0" ", 0x7070707, " "%0" "\n\t" "v_and_b32 " "%1" ", 0x7070707, " "%1" "\n\t" "v_and_b32 " "%2" ", 0x7070707, " "%2" "\n\t" "v_and_b32 " "%3" ", 0x7070707, " "%3" "\n\t" "v_and_b32 " "%4" ", 0x7070707, " "%4" "\n\t" "v_and_b32 " "%5" ", 0x7070707, " "%5" "\n\t" "v_and_b32 " "%6" ", 0x7070707, " "%6" "\n\t" "v_and_b32 " "%7" ", 0x7070707, " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_and_b32_e64 {
+    static constexpr const char* name = "v_and_b32_e64";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_and_b32_e64 " "%0" ", " "%0" ", %8\n\t" "v_and_b32_e64 " "%1" ", " "%1" ", %8\n\t" "v_and_b32_e64 " "%2" ", " "%2" ", %8\n\t" "v_and_b32_e64 " "%3" ", " "%3" ", %8\n\t" "v_and_b32_e64 " "%4" ", " "%4" ", %8\n\t" "v_and_b32_e64 " "%5" ", " "%5" ", %8\n\t" "v_and_b32_e64 " "%6" ", " "%6" ", %8\n\t" "v_and_b32_e64 " "%7" ", " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_add_u32_literal {
+    static constexpr const char* name = "v_add_u32_literal";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_add_u32 " "%0" ", 0x7c7c7c7c, " "%0" "\n\t" "v_add_u32 " "%1" ", 0x7c7c7c7c, " "%1" "\n\t" "v_add_u32 " "%2" ", 0x7c7c7c7c, " "%2" "\n\t" "v_add_u32 " "%3" ", 0x7c7c7c7c, " "%3" "\n\t" "v_add_u32 " "%4" ", 0x7c7c7c7c, " "%4" "\n\t" "v_add_u32 " "%5" ", 0x7c7c7c7c, " "%5" "\n\t" "v_add_u32 " "%6" ", 0x7c7c7c7c, " "%6" "\n\t" "v_add_u32 " "%7" ", 0x7c7c7c7c, " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_lshlrev_b32_imm {
+    static constexpr const char* name = "v_lshlrev_b32_imm";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_lshlrev_b32 " "%0" ", 2, " "%0" "\n\t" "v_lshlrev_b32 " "%1" ", 2, " "%1" "\n\t" "v_lshlrev_b32 " "%2" ", 2, " "%2" "\n\t" "v_lshlrev_b32 " "%3" ", 2, " "%3" "\n\t" "v_lshlrev_b32 " "%4" ", 2, " "%4" "\n\t" "v_lshlrev_b32 " "%5" ", 2, " "%5" "\n\t" "v_lshlrev_b32 " "%6" ", 2, " "%6" "\n\t" "v_lshlrev_b32 " "%7" ", 2, " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_lshrrev_b32_imm {
+    static constexpr const char* name = "v_lshrrev_b32_imm";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_lshrrev_b32 " "%0" ", 7, " "%0" "\n\t" "v_lshrrev_b32 " "%1" ", 7, " "%1" "\n\t" "v_lshrrev_b32 " "%2" ", 7, " "%2" "\n\t" "v_lshrrev_b32 " "%3" ", 7, " "%3" "\n\t" "v_lshrrev_b32 " "%4" ", 7, " "%4" "\n\t" "v_lshrrev_b32 " "%5" ", 7, " "%5" "\n\t" "v_lshrrev_b32 " "%6" ", 7, " "%6" "\n\t" "v_lshrrev_b32 " "%7" ", 7, " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_or_b32 {
+    static constexpr const char* name = "v_or_b32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_or_b32 " "%0" ", " "%0" ", %8\n\t" "v_or_b32 " "%1" ", " "%1" ", %8\n\t" "v_or_b32 " "%2" ", " "%2" ", %8\n\t" "v_or_b32 " "%3" ", " "%3" ", %8\n\t" "v_or_b32 " "%4" ", " "%4" ", %8\n\t" "v_or_b32 " "%5" ", " "%5" ", %8\n\t" "v_or_b32 " "%6" ", " "%6" ", %8\n\t" "v_or_b32 " "%7" ", " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_xor_b32 {
+    static constexpr const char* name = "v_xor_b32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_xor_b32 " "%0" ", " "%0" ", %8\n\t" "v_xor_b32 " "%1" ", " "%1" ", %8\n\t" "v_xor_b32 " "%2" ", " "%2" ", %8\n\t" "v_xor_b32 " "%3" ", " "%3" ", %8\n\t" "v_xor_b32 " "%4" ", " "%4" ", %8\n\t" "v_xor_b32 " "%5" ", " "%5" ", %8\n\t" "v_xor_b32 " "%6" ", " "%6" ", %8\n\t" "v_xor_b32 " "%7" ", " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_mov_b32 {
+    static constexpr const char* name = "v_mov_b32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_mov_b32 " "%0" ", %8\n\t" "v_mov_b32 " "%1" ", %8\n\t" "v_mov_b32 " "%2" ", %8\n\t" "v_mov_b32 " "%3" ", %8\n\t" "v_mov_b32 " "%4" ", %8\n\t" "v_mov_b32 " "%5" ", %8\n\t" "v_mov_b32 " "%6" ", %8\n\t" "v_mov_b32 " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_not_b32 {
+    static constexpr const char* name = "v_not_b32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_not_b32 " "%0" ", " "%0" "\n\t" "v_not_b32 " "%1" ", " "%1" "\n\t" "v_not_b32 " "%2" ", " "%2" "\n\t" "v_not_b32 " "%3" ", " "%3" "\n\t" "v_not_b32 " "%4" ", " "%4" "\n\t" "v_not_b32 " "%5" ", " "%5" "\n\t" "v_not_b32 " "%6" ", " "%6" "\n\t" "v_not_b32 " "%7" ", " "%7" "\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_sub_u32 {
+    static constexpr const char* name = "v_sub_u32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_sub_u32 " "%0" ", " "%0" ", %8\n\t" "v_sub_u32 " "%1" ", " "%1" ", %8\n\t" "v_sub_u32 " "%2" ", " "%2" ", %8\n\t" "v_sub_u32 " "%3" ", " "%3" ", %8\n\t" "v_sub_u32 " "%4" ", " "%4" ", %8\n\t" "v_sub_u32 " "%5" ", " "%5" ", %8\n\t" "v_sub_u32 " "%6" ", " "%6" ", %8\n\t" "v_sub_u32 " "%7" ", " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_max_u32 {
+    static constexpr const char* name = "v_max_u32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_max_u32 " "%0" ", " "%0" ", %8\n\t" "v_max_u32 " "%1" ", " "%1" ", %8\n\t" "v_max_u32 " "%2" ", " "%2" ", %8\n\t" "v_max_u32 " "%3" ", " "%3" ", %8\n\t" "v_max_u32 " "%4" ", " "%4" ", %8\n\t" "v_max_u32 " "%5" ", " "%5" ", %8\n\t" "v_max_u32 " "%6" ", " "%6" ", %8\n\t" "v_max_u32 " "%7" ", " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_bfi_b32 {
+    static constexpr const char* name = "v_bfi_b32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_bfi_b32 " "%0" ", %9, " "%0" ", %8\n\t" "v_bfi_b32 " "%1" ", %9, " "%1" ", %8\n\t" "v_bfi_b32 " "%2" ", %9, " "%2" ", %8\n\t" "v_bfi_b32 " "%3" ", %9, " "%3" ", %8\n\t" "v_bfi_b32 " "%4" ", %9, " "%4" ", %8\n\t" "v_bfi_b32 " "%5" ", %9, " "%5" ", %8\n\t" "v_bfi_b32 " "%6" ", %9, " "%6" ", %8\n\t" "v_bfi_b32 " "%7" ", %9, " "%7" ", %8\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_add3_u32 {
+    static constexpr const char* name = "v_add3_u32";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_add3_u32 " "%0" ", " "%0" ", %8, %9\n\t" "v_add3_u32 " "%1" ", " "%1" ", %8, %9\n\t" "v_add3_u32 " "%2" ", " "%2" ", %8, %9\n\t" "v_add3_u32 " "%3" ", " "%3" ", %8, %9\n\t" "v_add3_u32 " "%4" ", " "%4" ", %8, %9\n\t" "v_add3_u32 " "%5" ", " "%5" ", %8, %9\n\t" "v_add3_u32 " "%6" ", " "%6" ", %8, %9\n\t" "v_add3_u32 " "%7" ", " "%7" ", %8, %9\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_and_then_v_perm {
+    static constexpr const char* name = "v_and_then_v_perm";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_and_b32 " "%0" ", " "%0" ", %8\n\tv_perm_b32 " "%0" ", " "%0" ", %8, %9\n\t" "v_and_b32 " "%1" ", " "%1" ", %8\n\tv_perm_b32 " "%1" ", " "%1" ", %8, %9\n\t" "v_and_b32 " "%2" ", " "%2" ", %8\n\tv_perm_b32 " "%2" ", " "%2" ", %8, %9\n\t" "v_and_b32 " "%3" ", " "%3" ", %8\n\tv_perm_b32 " "%3" ", " "%3" ", %8, %9\n\t" "v_and_b32 " "%4" ", " "%4" ", %8\n\tv_perm_b32 " "%4" ", " "%4" ", %8, %9\n\t" "v_and_b32 " "%5" ", " "%5" ", %8\n\tv_perm_b32 " "%5" ", " "%5" ", %8, %9\n\t" "v_and_b32 " "%6" ", " "%6" ", %8\n\tv_perm_b32 " "%6" ", " "%6" ", %8, %9\n\t" "v_and_b32 " "%7" ", " "%7" ", %8\n\tv_perm_b32 " "%7" ", " "%7" ", %8, %9\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_and_x3_then_v_perm {
+    static constexpr const char* name = "v_and_x3_then_v_perm";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_and_b32 " "%0" ", " "%0" ", %8\n\tv_or_b32 " "%0" ", " "%0" ", %8\n\tv_xor_b32 " "%0" ", " "%0" ", %8\n\tv_perm_b32 " "%0" ", " "%0" ", %8, %9\n\t" "v_and_b32 " "%1" ", " "%1" ", %8\n\tv_or_b32 " "%1" ", " "%1" ", %8\n\tv_xor_b32 " "%1" ", " "%1" ", %8\n\tv_perm_b32 " "%1" ", " "%1" ", %8, %9\n\t" "v_and_b32 " "%2" ", " "%2" ", %8\n\tv_or_b32 " "%2" ", " "%2" ", %8\n\tv_xor_b32 " "%2" ", " "%2" ", %8\n\tv_perm_b32 " "%2" ", " "%2" ", %8, %9\n\t" "v_and_b32 " "%3" ", " "%3" ", %8\n\tv_or_b32 " "%3" ", " "%3" ", %8\n\tv_xor_b32 " "%3" ", " "%3" ", %8\n\tv_perm_b32 " "%3" ", " "%3" ", %8, %9\n\t" "v_and_b32 " "%4" ", " "%4" ", %8\n\tv_or_b32 " "%4" ", " "%4" ", %8\n\tv_xor_b32 " "%4" ", " "%4" ", %8\n\tv_perm_b32 " "%4" ", " "%4" ", %8, %9\n\t" "v_and_b32 " "%5" ", " "%5" ", %8\n\tv_or_b32 " "%5" ", " "%5" ", %8\n\tv_xor_b32 " "%5" ", " "%5" ", %8\n\tv_perm_b32 " "%5" ", " "%5" ", %8, %9\n\t" "v_and_b32 " "%6" ", " "%6" ", %8\n\tv_or_b32 " "%6" ", " "%6" ", %8\n\tv_xor_b32 " "%6" ", " "%6" ", %8\n\tv_perm_b32 " "%6" ", " "%6" ", %8, %9\n\t" "v_and_b32 " "%7" ", " "%7" ", %8\n\tv_or_b32 " "%7" ", " "%7" ", %8\n\tv_xor_b32 " "%7" ", " "%7" ", %8\n\tv_perm_b32 " "%7" ", " "%7" ", %8, %9\n\t"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+
 template <typename OP>
 __global__ __launch_bounds__(1024) void k_op(uint64_t* cyc, uint32_t* sink, int iters) {
     uint32_t a[8];
@@ -322,14 +468,21 @@ __global__ __launch_bounds__(1024) void k_window(uint64_t* cyc, uint32_t* sink, 
 
 static uint64_t* d_cyc;
 static uint32_t* d_sink;
+static float g_last_ms;  // wall time of the last timed launch (calibrates the s_memtime tick)
 
 template <typename F>
 double median_cycles(F launch, int nwaves) {
     launch(4);
     hipDeviceSynchronize();
     const int iters = 2048;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0);
     launch(iters);
+    hipEventRecord(e1);
     hipDeviceSynchronize();
+    hipEventElapsedTime(&g_last_ms, e0, e1);
     std::vector<uint64_t> c(nwaves);
     hipMemcpy(c.data(), d_cyc, nwaves * sizeof(uint64_t), hipMemcpyDeviceToHost);
     std::sort(c.begin(), c.end());
@@ -345,6 +498,7 @@ void run_op() {
             [&](int it) { hipLaunchKernelGGL(k_op<OP>, dim3(grid), dim3(wg), 0, 0, d_cyc, d_sink, it); }, grid * wg / 64);
         const double wps = threads / 256.0;
         printf("  %dw/SIMD %5.2f", static_cast<int>(wps), cyc / (32.0 * wps));
+        if (threads == 2048) printf("  [tick = %.3f ns]", g_last_ms * 1e6 / (cyc * 2048));
     }
     printf("   cycles per instruction per SIMD\n");
 }
@@ -388,6 +542,22 @@ int main() {
     run_op<v_readlane_b32>();
     run_op<s_mov_then_v_and>();
     run_op<v_and_then_s_nop>();
+    run_op<v_and_b32_sgpr>();
+    run_op<v_and_b32_literal>();
+    run_op<v_and_b32_e64>();
+    run_op<v_add_u32_literal>();
+    run_op<v_lshlrev_b32_imm>();
+    run_op<v_lshrrev_b32_imm>();
+    run_op<v_or_b32>();
+    run_op<v_xor_b32>();
+    run_op<v_mov_b32>();
+    run_op<v_not_b32>();
+    run_op<v_sub_u32>();
+    run_op<v_max_u32>();
+    run_op<v_bfi_b32>();
+    run_op<v_add3_u32>();
+    run_op<v_and_then_v_perm>();
+    run_op<v_and_x3_then_v_perm>();
     run_window<0>("window block (8 pos)");
     run_window<1>("window block + addr VALU");
     run_window<2>("8 ds_add, all lanes");

@@ -75,6 +75,9 @@ VKL_FN uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Three-operand VALU forms that hipcc does not select on gfx950 when one operand is a 32-bit
 // literal (VOP3 cannot encode literals on gfx9): spelled out, with the constant in an SGPR.
+// (Two-operand and / add / xor keep their constants as LITERALS: measured on gfx950 at 8 waves per
+// SIMD, tools/issue_rate.hip, a VOP2 with a literal issues at the full rate, the same instruction
+// with an SGPR operand at ~0.6 of it, any three-operand VOP3 / DPP / SDWA form at ~0.5.)
 // Plain VGPR-to-VGPR ALU instructions: no memory access, no extra wait states.
 VKL_FN uint32_t and_or_k(uint32_t a, uint32_t kmask, uint32_t c) {  // (a & kmask) | c
 #if defined(__HIP_DEVICE_COMPILE__)

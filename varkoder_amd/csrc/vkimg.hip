@@ -310,6 +310,9 @@ static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
     }
     if ((reinterpret_cast<uintptr_t>(d_fastq) & 15u) != 0) return VK_EINVAL;
     uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
+    // a wavefront addresses its byte range through a 32-bit buffer descriptor (vk_count.h, wave_stream):
+    // keep every range below 2 GiB, whatever the caller asked for
+    while (maxlen / (static_cast<uint64_t>(parts) * kWaves) >= (1ull << 31)) parts *= 2;
     if (static_cast<uint64_t>(nsamples) * parts > (1u << 24)) return VK_EINVAL;
 
     if (ctx->desc_cap < 2ull * nsamples * sizeof(uint64_t)) ctx->desc_n = 0;  // realloc drops the cached copy

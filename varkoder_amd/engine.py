@@ -280,11 +280,11 @@ def count_giant_sample(engine, data, rank=0, world=1):
     rank counts a record-aligned byte range of the FASTQ text on its own GPU, then the 4^k u32
     histograms are summed with one all-reduce (RCCL when the group is nccl).  Returns the full
     histogram tensor (identical on every rank) and this rank's status word."""
-    from .shard import allreduce_sum_, split_at_records
+    from .shard import allreduce_sum_, split_at_records, widen_u32
     start, end = split_at_records(data, world)[rank]
     part = data[start:end]
     dev, offs, lens = engine.upload([part])
     hist, status = engine.count(dev, offs, lens)
-    h = hist.view(-1).to(_torch().int64)      # sum in 64 bit, counts of a giant sample may pass 2^31
+    h = widen_u32(hist.view(-1))              # sum in 64 bit (unsigned widening): counts of a giant sample may pass 2^31
     allreduce_sum_(h)
     return h, int(status.cpu()[0])

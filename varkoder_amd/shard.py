@@ -95,6 +95,13 @@ def split_at_records(data, nparts, window=1 << 16):
     return [(cuts[i], cuts[i + 1]) for i in range(nparts)]
 
 
+def widen_u32(t):
+    """int64 copy of a tensor that holds UNSIGNED 32-bit counts in int32 storage (torch has no u32
+    arithmetic): a plain .to(int64) would sign-extend a count of 2^31 or more into a negative number."""
+    import torch
+    return t.to(torch.int64) & 0xFFFFFFFF
+
+
 def allreduce_sum_(hist):
     """In-place SUM all-reduce of a histogram tensor over the default group: the one data-path
     collective of this package (RCCL over xGMI when the group is `nccl`; 64 KB at k=7, 1 MB at
@@ -102,5 +109,10 @@ def allreduce_sum_(hist):
     result is exact and independent of the reduction order."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        if hist.is_cuda and dist.get_backend() != "nccl":   # gloo rehearsal of a GPU job: reduce on the host
+            h = hist.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            hist.copy_(h)
+        else:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist

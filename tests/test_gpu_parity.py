@@ -194,6 +194,27 @@ def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
         assert np.array_equal(got[1], want2), parts
 
 
+@pytest.mark.parametrize("k", (8, 9))
+def test_spill_path_with_a_full_arena_counts_directly(k, monkeypatch):
+    """The bucket streams of k = 8, 9 live in a per-sample arena of 4 KiB runs.  With the arena cut
+    to a handful of runs (VKIMG_SPILL_RUNS_CAP) most blocks find no room and must be counted with
+    global atomics instead: same histogram."""
+    from varkoder_amd.engine import ImageEngine
+    monkeypatch.setenv("VKIMG_SPILL_RUNS_CAP", "24")
+    eng = ImageEngine(k=k, mapping="cgr", device=0)
+    try:
+        samples = [synth.sample_fastq(40 + i, 6000, 150, dist=i & 1) for i in range(3)]
+        dev, offs, lens = eng.upload(samples)
+        for parts in (1, 3):
+            hist, status = eng.count(dev, offs, lens, parts=parts)
+            assert not status.cpu().numpy().any()
+            got = hist.cpu().numpy().view(np.uint32)
+            for i, fq in enumerate(samples):
+                assert np.array_equal(got[i], oracle.count_fastq(fq, k)[0]), (parts, i)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("k", KS)
 def test_count_fuzz_batches(engines, k):
     """Hundreds of random adversarial (well-formed) FASTQ samples per launch, random workgroup

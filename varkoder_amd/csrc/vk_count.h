@@ -327,11 +327,11 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t x) {
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-template <int K, bool SUB, int PF, typename Windows>
+template <int K, bool SUB, int PF, typename Windows, typename PieceStart>
 __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, uint64_t len_, uint64_t w0_,
                                             uint64_t w1_, uint64_t* scratch, const uint4* below, const uint4* above,
-                                            int lane, Windows windows, uint32_t& ph_start, uint32_t& ph_end,
-                                            SubWave& sw) {
+                                            int lane, Windows windows, PieceStart piece_start, uint32_t& ph_start,
+                                            uint32_t& ph_end, SubWave& sw) {
     // the range is the same for the whole wave: keep it (and everything derived from it: piece
     // addresses, loop counter, edge tests) in scalar registers
     const uint8_t* sbase = reinterpret_cast<const uint8_t*>(uniform64(reinterpret_cast<uint64_t>(sbase_)));
@@ -417,6 +417,10 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, 
             clip_granule(r3, n - 48);
         }
         const uint4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;  // this lane's 64 bytes
+        // the consumer's vector-memory work of the PREVIOUS piece goes out here, behind the wait for this
+        // piece's bytes: it then has a whole piece of arithmetic to retire before the next such wait
+        // (loads, stores and atomics share one in-order counter, vmcnt)
+        piece_start(q0);
         const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                 q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
         VK_STAMP(t1);
@@ -570,7 +574,8 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB, SUB ? 1 : VK_K1_PF>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB, SUB ? 1 : VK_K1_PF>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win,
+                                                [](const uint4&) {}, ph_start, ph_end, sw);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
     }
@@ -590,42 +595,77 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
 }
 
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
-// 4^K u32 counters do not fit LDS.  Pass A streams the FASTQ exactly like vk_count_kernel but
-// appends the windows, two at a time (see entry_raw), to one of 16 wave-private LDS queues chosen
-// by the two bases both windows of a pair share, and once per piece drains full 64-entry blocks (128 B) into
-// per-(sample, queue) bucket streams in HBM.  The drain handles all 16 queues at once, four lanes
-// per queue; block runs are reserved 32 at a time with one global atomic, unused run tails are
-// padded with 0xFFFF.  Pass B gives every (sample, queue) one workgroup that replays its stream into
-// a 2 x 4^K/16-bin LDS histogram (one half per entry type) and adds it to the global histogram.
-// Pairs that cannot be queued or whose bucket is full are counted with global atomics on the spot:
-// slower, still exact.
-constexpr uint32_t kQueues = 16;         // queues per wave = bucket streams per sample
-constexpr uint32_t kQueueCap = 256;      // u16 entries per queue (four blocks)
-constexpr uint32_t kQueueBlocks = 4;     // kQueueCap / kBlockEntries
-constexpr uint32_t kQueueShift = 7;      // log2(bytes per queue / bytes per counter)
-constexpr uint32_t kBlockEntries = 64;   // u16 entries per 128-byte bucket block
-constexpr uint32_t kRunBlocks = 32;      // blocks reserved per global atomic
+// 4^K u32 counters do not fit LDS.  Pass A (vk_bucket_kernel) streams the FASTQ exactly like
+// vk_count_kernel, but instead of counting it PARTITIONS the windows into 16 bucket streams per
+// sample; pass B (vk_bucket_count_kernel) gives every (sample, bucket) one workgroup that replays
+// its stream into a 2 x 4^K/16-bin LDS histogram and adds that to the global one.
+//
+// Two windows that end at neighbouring positions p, p + 1 (p even) overlap in K - 1 bases; the
+// bases p-1 and p, which both contain, are the bucket number q (4 bits) of the PAIR, and what is
+// left of the K + 1 bases of the pair is one u16 entry:
+//     bits [0, LB)      bases p-K+1 .. p-2   (LB = 2K - 4)
+//     bits [LB, LB+2)   base  p+1
+// i.e. ONE byte of bucket traffic per window (written once, read once).  Pairs of which only one
+// window is countable (a read's first or last window, the neighbours of an N: ~1.3 per read) are
+// "singles" and are counted with a global atomic on the spot, as is everything that does not fit a
+// queue or the arena (low-complexity input) -- slower, still exact.
+//
+// Queues: 16 per wavefront in LDS, 128 entries each; a queue is drained in 64-byte blocks (32
+// entries), all 16 queues at once (four lanes per queue), whenever one holds two blocks.  Blocks go
+// to RUNS of 4 KiB that a wave takes from the sample's arena with one global atomic; a closed run's
+// header word says which bucket it belongs to and how many of its blocks are filled, so no stream
+// has a fixed capacity: however skewed the base composition, the arena holds all pairs of the
+// sample (at most len / 4 of them) plus one open run per (wave, queue).
+constexpr uint32_t kQueues = 16;          // queues per wave = bucket streams per sample
+constexpr uint32_t kQueueBytes = 256;     // 128 u16 entries
+constexpr uint32_t kQueueShift = 6;       // log2(kQueueBytes / 4): data offset = counter offset << 6
+constexpr uint32_t kBlockBytes = 64;      // drain unit
+constexpr uint32_t kQueueBlocks = kQueueBytes / kBlockBytes;
+constexpr uint32_t kRunBytes = 4096;      // arena allocation unit
+constexpr uint32_t kRunBlocks = kRunBytes / kBlockBytes;
+constexpr uint32_t kDrainAt = 2 * kBlockBytes;  // inside a piece: drain when some queue holds this many bytes
+constexpr uint32_t kNoRun = 0x100;        // "blocks used" of a queue that has no run open
 
 struct BucketParams {
-    uint32_t* cursors;   // [nsamples][16] next free block of each bucket stream
-    uint32_t* buckets;   // [nsamples][16][cap_blocks * 32] dwords
-    uint32_t cap_blocks; // multiple of kRunBlocks
+    uint32_t* cursors;   // [nsamples] next free run of the sample's arena
+    uint32_t* hdrs;      // [nsamples][runs_cap] 0x80000000 | filled blocks << 8 | bucket, 0 = never closed
+    uint8_t* arena;      // [nsamples][runs_cap][kRunBytes]
+    uint32_t* bucket_hist;  // [nsamples][16][2 * 4^K / 16] pass B's counters, merged into the histogram by pass C
+    uint32_t runs_cap;
 };
 
-// Bucket entries (u16, 0xFFFF = padding).  Two windows that end at neighbouring positions p, p + 1
-// (p even) share the bases p-1 and p; those four bits are the queue number q of BOTH, so one
-// returning LDS atomic and one 32-bit store queue the pair.  LB = 2K - 4 bits remain per window:
-//   low half,  type 0 (window ending at p):     bases p-K+1 .. p-2
-//   high half, type 1 (window ending at p + 1): bases p-K+2 .. p-2, then base p+1
-// The type is the half of the dword the entry sits in (blocks move as whole 128-byte units, so the
-// halves never mix).  entry_raw rebuilds the raw window field (first base least significant) from
-// rest | type << LB.
+// LDS of the bucket kernel, one array with fixed offsets (the hand-written queue appends address it
+// with immediate offsets, so it must be the kernel's only LDS object and start at 0: checked at run time)
+constexpr uint32_t kLdsCnt = 0;                                   // u32 [kWaves][16] queue fill in bytes
+constexpr uint32_t kLdsRun = kLdsCnt + kWaves * kQueues * 4;      // u32 [kWaves][16] current run of the queue
+constexpr uint32_t kLdsUsed = kLdsRun + kWaves * kQueues * 4;     // u32 [kWaves][16] blocks used in it (kNoRun = none open)
+constexpr uint32_t kLdsScratch = kLdsUsed + kWaves * kQueues * 4; // u64 [kWaves][8]
+constexpr uint32_t kLdsBelow = kLdsScratch + kWaves * 64;         // uint4 [66]
+constexpr uint32_t kLdsAbove = kLdsBelow + 66 * 16;               // uint4 [66]
+constexpr uint32_t kLdsQueues = 8192;                             // u16 [kWaves][16][128]
+constexpr uint32_t kLdsBucketBytes = kLdsQueues + kWaves * kQueues * kQueueBytes;
+static_assert(kLdsAbove + 66 * 16 <= kLdsQueues, "LDS layout");
+static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");
+
+// Raw window field (first base least significant) of the window of type t (0: ends at p, 1: ends at
+// p + 1) of a pair entry e of bucket q:  t = 0: rest | q << LB;  t = 1: rest without its first base,
+// then q, then the base p+1.  `idx` = the 14-bit (K = 9) index pass B counts it under: rest for
+// type 0, (rest >> 2) | last << (LB - 2) for type 1.
 template <int K>
-__device__ __forceinline__ uint32_t entry_raw(uint32_t q, uint32_t e) {
+__device__ __forceinline__ uint32_t entry_raw(uint32_t q, uint32_t idx_and_type) {
     constexpr uint32_t LB = 2 * K - 4;
-    const uint32_t rest = e & ((1u << LB) - 1u);
-    if ((e >> LB) == 0u) return (q << LB) | rest;
-    return (rest & ((1u << (LB - 2)) - 1u)) | (q << (LB - 2)) | ((rest >> (LB - 2)) << (2 * K - 2));
+    const uint32_t idx = idx_and_type & ((1u << LB) - 1u);
+    if ((idx_and_type >> LB) == 0u) return (q << LB) | idx;
+    return (idx & ((1u << (LB - 2)) - 1u)) | (q << (LB - 2)) | ((idx >> (LB - 2)) << (2 * K - 2));
+}
+
+// both windows of the pair entry e (u16, upper garbage bits allowed for K = 8) of bucket q, counted directly
+template <int K>
+__device__ __forceinline__ void count_entry_direct(uint32_t* hist_s, uint32_t q, uint32_t e) {
+    constexpr uint32_t LB = 2 * K - 4;
+    const uint32_t rest = e & ((1u << LB) - 1u), last = (e >> LB) & 3u;
+    atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, rest), K)], 1u);
+    atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, (1u << LB) | (rest >> 2) | (last << (LB - 2))), K)], 1u);
 }
 
 __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
@@ -633,35 +673,41 @@ __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane 
 }
 
 template <int K, bool SUB>
-__global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
+__global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t LB = 2 * K - 4;               // local bits of an entry
+    constexpr uint32_t LB = 2 * K - 4;               // bits of an entry that come from the shared prefix
     constexpr uint32_t LMASK = (1u << LB) - 1u;
-    static_assert(LB <= 15, "entries are u16 with 0xFFFF as padding");
+    constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
+    static_assert(LB + 2 <= 16, "entries are u16");
 
-    __shared__ uint64_t scratch[kWaves][8];  // sync_phase: newline positions after a range start
-    __shared__ uint4 below[66];
-    __shared__ uint4 above[66];
-    __shared__ uint4 qbuf[kWaves][kQueues * kQueueCap / 8];  // u16 entries, eight per uint4
-    __shared__ uint32_t qcnt[kWaves][kQueues];
-    __shared__ uint32_t runbase[kWaves][kQueues];
-    __shared__ uint32_t runleft[kWaves][kQueues];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsBucketBytes / 4];
+    auto lds_addr = [](const void* p) {
+        return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
+    };
+    if (lds_addr(lds) != 0u) __builtin_trap();  // see kLdsCnt: never taken, the array is the kernel's only LDS object
+    uint8_t* const ldsb = reinterpret_cast<uint8_t*>(lds);
+    uint32_t* const qcnt_all = reinterpret_cast<uint32_t*>(ldsb + kLdsCnt);
+    uint32_t* const qrun_all = reinterpret_cast<uint32_t*>(ldsb + kLdsRun);
+    uint32_t* const qused_all = reinterpret_cast<uint32_t*>(ldsb + kLdsUsed);
+    uint64_t* const scratch_all = reinterpret_cast<uint64_t*>(ldsb + kLdsScratch);
+    uint4* const below = reinterpret_cast<uint4*>(ldsb + kLdsBelow);
+    uint4* const above = reinterpret_cast<uint4*>(ldsb + kLdsAbove);
 
     const uint32_t unit = blockIdx.x;
     const uint32_t s = unit / parts;
     const uint32_t part = unit % parts;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     fill_mask_tables(below, above, tid);
     if (lane < static_cast<int>(kQueues)) {
-        qcnt[wave][lane] = 0u;
-        runbase[wave][lane] = 0u;
-        runleft[wave][lane] = 0u;
+        qcnt_all[wave * kQueues + lane] = 0u;
+        qrun_all[wave * kQueues + lane] = 0u;
+        qused_all[wave * kQueues + lane] = kNoRun;
     }
     __syncthreads();
 
@@ -669,137 +715,197 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
     const uint64_t len = lens[s];
     const WaveRange wr = wave_range(len, parts, part, wave);
     uint32_t* hist_s = hist_out + static_cast<uint64_t>(s) * NCODE;
-    uint16_t* q16 = reinterpret_cast<uint16_t*>(&qbuf[wave][0]);
 
-    // Four lanes per queue: q = lane / 4, every lane moves 32 B of a 128-byte block.
+    // Four lanes per queue: q = lane / 4, every lane moves 16 B of a 64-byte block.
     const uint32_t q = static_cast<uint32_t>(lane) >> 2, sub = static_cast<uint32_t>(lane) & 3u;
-    const uint32_t cap_blocks = bp.cap_blocks;
-    uint32_t* const cursor = bp.cursors + (s * kQueues + q);
-    uint4* const gq = reinterpret_cast<uint4*>(bp.buckets + (static_cast<uint64_t>(s) * kQueues + q) * cap_blocks * 32u);
+    uint32_t* const qcnt = qcnt_all + wave * kQueues;
+    uint32_t* const qrun = qrun_all + wave * kQueues;
+    uint32_t* const qused = qused_all + wave * kQueues;
+    uint8_t* const qdata = ldsb + kLdsQueues + (wave * kQueues + q) * kQueueBytes;  // this lane's queue
+    uint32_t* const cursor = bp.cursors + s;
+    uint32_t* const hdrs = bp.hdrs + static_cast<uint64_t>(s) * bp.runs_cap;
+    uint8_t* const arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
+    const uint32_t runs_cap = bp.runs_cap;
 
-    // Drain `nb` (0..2, per queue) blocks from the front of every queue.  All lanes call it.
+    // Move the full blocks of every queue (nb = 0..4 of them, n = its fill in bytes) to the arena.
+    // All lanes call it; nb and n are the same in the four lanes of a queue.
     auto drain_all = [&](uint32_t n, uint32_t nb) __attribute__((always_inline)) {
-        uint32_t base = runbase[wave][q], left = runleft[wave][q];
-        const bool need = nb > left;
-        if (need) {  // the rest of the old run (fewer than nb <= 4 blocks) stays padding
-            const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            for (uint32_t b = 0; b < left; ++b) {
-                gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = ff;
-                gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = ff;
-            }
-        }
-        uint32_t nbase = 0;
-        if (need && sub == 0) nbase = atomicAdd(cursor, kRunBlocks);
-        nbase = quad_bcast0(nbase);
+        uint32_t run = qrun[q], used = qused[q];
+        const bool need = nb != 0u && used + nb > kRunBlocks;  // the blocks of one drain stay in one run
+        if (need && sub == 0 && used <= kRunBlocks) hdrs[run] = 0x80000000u | (used << 8) | q;  // close the old run
+        uint32_t nrun = 0;
+        if (need && sub == 0) nrun = atomicAdd(cursor, 1u);
+        nrun = quad_bcast0(nrun);
         if (need) {
-            base = nbase;
-            left = (nbase + kRunBlocks <= cap_blocks) ? kRunBlocks : 0u;
+            run = nrun;
+            used = nrun < runs_cap ? 0u : kNoRun;  // arena exhausted: no run open, the blocks are counted directly
         }
-        const bool store = left >= nb;  // false only when the bucket is full
-        const uint4* src = &qbuf[wave][q * (kQueueCap / 8)];
+        const bool store = used + nb <= kRunBlocks;
+        const uint4* src = reinterpret_cast<const uint4*>(qdata) + sub;
+        uint4* dst = reinterpret_cast<uint4*>(arena + static_cast<uint64_t>(run) * kRunBytes + used * kBlockBytes) + sub;
 #pragma unroll
         for (uint32_t b = 0; b < kQueueBlocks; ++b) {
             if (b < nb) {
-                const uint4 v0 = src[b * 8u + sub * 2u], v1 = src[b * 8u + sub * 2u + 1u];
+                const uint4 v = src[b * 4u];
                 if (store) {
-                    gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = v0;
-                    gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = v1;
-                } else {  // bucket full: count these entries directly (exact, slow)
-                    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
-                        if (lo != 0xFFFFu) atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, lo), K)], 1u);
-                        if (hi != 0xFFFFu) atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, hi | (1u << LB)), K)], 1u);
-                    }
+                    dst[b * 4u] = v;
+                } else {  // no room in the arena: count these entries directly (exact, slow; kept small)
+                    const uint16_t* e16 = reinterpret_cast<const uint16_t*>(qdata) + b * (kBlockBytes / 2) + sub * 8u;
+#pragma nounroll
+                    for (int j = 0; j < 8; ++j) count_entry_direct<K>(hist_s, q, e16[j]);
                 }
             }
         }
-        // move the remainder (< one block) to the front: block nb -> block 0 (after kQueueBlocks
-        // blocks nothing is left)
+        // move the remainder (< one block) to the front
         const bool tail = nb != 0u && nb < kQueueBlocks;
-        uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
-        if (tail) {
-            k0 = src[nb * 8u + sub * 2u];
-            k1 = src[nb * 8u + sub * 2u + 1u];
+        uint4 keep = make_uint4(0, 0, 0, 0);
+        if (tail) keep = src[nb * 4u];
+        wave_lds_fence();
+        if (tail) reinterpret_cast<uint4*>(qdata)[sub] = keep;
+        if (nb != 0u && sub == 0) {
+            qcnt[q] = n - nb * kBlockBytes;
+            qrun[q] = run;
+            qused[q] = store ? used + nb : used;
         }
         wave_lds_fence();
-        if (tail) {
-            qbuf[wave][q * (kQueueCap / 8) + sub * 2u] = k0;
-            qbuf[wave][q * (kQueueCap / 8) + sub * 2u + 1u] = k1;
-        }
-        if (nb && sub == 0) {
-            qcnt[wave][q] = 2u * (n - nb * kBlockEntries);
-            runbase[wave][q] = store ? base + nb : base;
-            runleft[wave][q] = store ? left - nb : 0u;
-        }
+    };
+    auto maybe_drain = [&](uint32_t at_least) __attribute__((always_inline)) {
         wave_lds_fence();
+        uint32_t n = qcnt[q];
+        if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
+        if (__any(n >= at_least)) drain_all(n, n / kBlockBytes);
     };
 
     uint32_t ph_start = 0, ph_end = 0;
     if (!wr.empty) {
-        // LDS byte addresses: the wave's 16 counters (which count BYTES, 4 per pair) and its queues
-        auto lds_addr = [](const void* p) {
-            return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) void*)p));
-        };
-        const uint32_t cnt_base = lds_addr(&qcnt[wave][0]);
-        // data address of queue qq = (counter address << kQueueShift) + data_skew, counters being 4 B apart
-        const uint32_t data_skew = lds_addr(&qbuf[wave][0]) - (cnt_base << kQueueShift);
-        // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
-        // `bit + 2` = the window ending at p / p + 1 is countable.  A missing partner becomes padding.
-        // x = the K + 1 bases p-K+1 .. p+1 (2 bits each, first base lowest); okw bits `bit` and
-        // `bit + 2` = the window ending at p / p + 1 is countable.  A missing partner becomes padding.
-        // (Issuing the atomics of four pairs back to back behind one wait was measured: 3 % slower,
-        // the loop is bound by VALU + SALU issue, not by the LDS round trip.)
-        auto emit_pair = [&](uint32_t x, uint32_t okw, int bit) __attribute__((always_inline)) {
-            constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
-            const uint32_t caddr = cnt_base + 4u * __builtin_amdgcn_ubfe(x, LB, 4);
-            uint32_t at;  // returning LDS atomic on the queue's byte counter
-            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(at) : "v"(caddr), "v"(4u) : "memory");
-            const uint32_t rest_a = x & LMASK;
-            // bit-field extracts spelled out: hipcc turns the builtins back into shift pairs here
-            uint32_t low_b, top_b, keep0, keep1;
-            asm("v_bfe_u32 %0, %1, 2, %2" : "=v"(low_b) : "v"(x), "n"(LB - 2));
-            asm("v_bfe_u32 %0, %1, %2, 2" : "=v"(top_b) : "v"(x), "n"(2 * K));
-            const uint32_t rest_b = (top_b << (LB - 2)) | low_b;
-            // all ones where the window counts: 0xFFFF in the half of a window that does not
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep0) : "v"(okw), "n"(bit));
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep1) : "v"(okw), "n"(bit + 2));
-            const uint32_t w = (rest_a | (rest_b << 16)) | ~__builtin_amdgcn_perm(keep1, keep0, 0x05040100u);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(at) : : "memory");
-            if (at < 2u * kQueueCap) {
-                const uint32_t daddr = (caddr << kQueueShift) + data_skew + at;
-                asm volatile("ds_write_b32 %0, %1" : : "v"(daddr), "v"(w) : "memory");
-            } else {  // queue full: exact slow path
-                if (keep0) atomicAdd(&hist_s[pair_reverse(x & FMASK, K)], 1u);
-                if (keep1) atomicAdd(&hist_s[pair_reverse((x >> 2) & FMASK, K)], 1u);
+        const uint32_t wbase = static_cast<uint32_t>(wave) * (kQueues * 4u);  // this wave's counters, relative to kLdsCnt
+        const uint32_t two = 2u;
+        // Append four pairs.  x[j] = the K + 1 bases of pair j (2 bits each, first base lowest, garbage
+        // above), f[j] != 0 <=> both windows of the pair are countable.  Straight-line code: the lane
+        // predicates are parked in SGPR pairs, the four returning atomics on the queue counters go out
+        // back to back, each append then waits only for its own counter value.  Returns, per lane, a mask
+        // of the pairs that found their queue full (they are counted directly by the caller).
+        auto append4 = [&](const uint32_t (&x)[4], const uint32_t (&f)[4]) __attribute__((always_inline)) -> uint32_t {
+            uint32_t c[4], e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // counter offset: q * 4 + this wave's base; entry: shared-prefix bits | base p+1
+                c[j] = ((x[j] >> (2 * K - 6)) & 0x3Cu) | wbase;
+                e[j] = (x[j] & LMASK) | ((x[j] >> 4) & ~LMASK);  // one v_bfi: base p+1 moves down over the four bucket bits (garbage above it)
             }
+            uint32_t a0, a1, a2, a3;
+            unsigned long long m0, m1, m2, m3, k0, k1, k2, k3;
+            const uint32_t cap = kQueueBytes;
+            asm volatile(
+                "v_cmp_ne_u32_e64 %[m0], 0, %[f0]\n\t"
+                "v_cmp_ne_u32_e64 %[m1], 0, %[f1]\n\t"
+                "v_cmp_ne_u32_e64 %[m2], 0, %[f2]\n\t"
+                "v_cmp_ne_u32_e64 %[m3], 0, %[f3]\n\t"
+                "s_mov_b64 exec, %[m0]\n\tds_add_rtn_u32 %[a0], %[c0], %[two]\n\t"
+                "s_mov_b64 exec, %[m1]\n\tds_add_rtn_u32 %[a1], %[c1], %[two]\n\t"
+                "s_mov_b64 exec, %[m2]\n\tds_add_rtn_u32 %[a2], %[c2], %[two]\n\t"
+                "s_mov_b64 exec, %[m3]\n\tds_add_rtn_u32 %[a3], %[c3], %[two]\n\t"
+                "s_mov_b64 exec, %[m0]\n\ts_waitcnt lgkmcnt(3)\n\t"
+                "v_cmp_gt_u32_e64 %[k0], %[cap], %[a0]\n\tv_lshl_add_u32 %[a0], %[c0], 6, %[a0]\n\t"
+                "s_mov_b64 exec, %[k0]\n\tds_write_b16 %[a0], %[e0] offset:%[qb]\n\t"
+                "s_mov_b64 exec, %[m1]\n\ts_waitcnt lgkmcnt(3)\n\t"
+                "v_cmp_gt_u32_e64 %[k1], %[cap], %[a1]\n\tv_lshl_add_u32 %[a1], %[c1], 6, %[a1]\n\t"
+                "s_mov_b64 exec, %[k1]\n\tds_write_b16 %[a1], %[e1] offset:%[qb]\n\t"
+                "s_mov_b64 exec, %[m2]\n\ts_waitcnt lgkmcnt(3)\n\t"
+                "v_cmp_gt_u32_e64 %[k2], %[cap], %[a2]\n\tv_lshl_add_u32 %[a2], %[c2], 6, %[a2]\n\t"
+                "s_mov_b64 exec, %[k2]\n\tds_write_b16 %[a2], %[e2] offset:%[qb]\n\t"
+                "s_mov_b64 exec, %[m3]\n\ts_waitcnt lgkmcnt(3)\n\t"
+                "v_cmp_gt_u32_e64 %[k3], %[cap], %[a3]\n\tv_lshl_add_u32 %[a3], %[c3], 6, %[a3]\n\t"
+                "s_mov_b64 exec, %[k3]\n\tds_write_b16 %[a3], %[e3] offset:%[qb]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_andn2_b64 %[m0], %[m0], %[k0]\n\t"
+                "s_andn2_b64 %[m1], %[m1], %[k1]\n\t"
+                "s_andn2_b64 %[m2], %[m2], %[k2]\n\t"
+                "s_andn2_b64 %[m3], %[m3], %[k3]"
+                : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [m0] "=&s"(m0), [m1] "=&s"(m1),
+                  [m2] "=&s"(m2), [m3] "=&s"(m3), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
+                : [f0] "v"(f[0]), [f1] "v"(f[1]), [f2] "v"(f[2]), [f3] "v"(f[3]), [c0] "v"(c[0]), [c1] "v"(c[1]),
+                  [c2] "v"(c[2]), [c3] "v"(c[3]), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
+                  [two] "v"(two), [cap] "s"(cap), [qb] "i"(kLdsQueues)
+                : "memory");
+            // m_j now holds the lanes whose pair j found its queue full
+            if ((m0 | m1 | m2 | m3) == 0ull) return 0u;  // wave-uniform; the rule
+            const unsigned long long me = 1ull << lane;
+            return ((m0 & me) ? 1u : 0u) | ((m1 & me) ? 2u : 0u) | ((m2 & me) ? 4u : 0u) | ((m3 & me) ? 8u : 0u);
         };
-        auto after_group = [&]() __attribute__((always_inline)) {
-            wave_lds_fence();
-            uint32_t n = qcnt[wave][q] >> 1;  // bytes -> entries
-            if (n > kQueueCap) n = kQueueCap;
-            const uint32_t nb = n / kBlockEntries;
-            if (__any(nb != 0u)) drain_all(n, nb);
+        // one countable window (raw field in the low 2K bits of x), straight to the histogram
+        auto count_direct = [&](uint32_t x) __attribute__((always_inline)) {
+            atomicAdd(&hist_s[pair_reverse(x & FMASK, K)], 1u);
+        };
+        // Singles wait in two registers per lane until the start of the next piece (piece_start): a
+        // global atomic issued in the window stage would still be in flight at the wait for the next
+        // piece's bytes, and every wave would sit out its round trip to the memory-side atomic unit.
+        uint32_t pend0 = 0, pend1 = 0, npend = 0;
+        auto single = [&](uint32_t x) __attribute__((always_inline)) {
+            const uint32_t code = pair_reverse(x & FMASK, K);
+            if (npend == 0u) pend0 = code;
+            else if (npend == 1u) pend1 = code;
+            else atomicAdd(&hist_s[code], 1u);  // a third single of this lane in one piece (reads full of N)
+            ++npend;
+        };
+        auto piece_start = [&](const uint4&) __attribute__((always_inline)) {
+            if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
+            if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
+            npend = 0u;
+            maybe_drain(kBlockBytes);  // the queues as the previous piece left them: every full block goes out now
         };
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
             const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                // bit 4j of `both` / `one`: both / exactly one of the windows ending at 16g + 2j, 16g + 2j + 1 count
+                const uint32_t both = ok[g] & (ok[g] >> 2) & 0x11111111u;
+                const uint32_t one = (ok[g] ^ (ok[g] >> 2)) & 0x11111111u;
+                if (__any((both | one) != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int p = 16 * g + 2 * j;  // windows ending at p and p + 1
-                    if (ok[g] & (5u << (4 * j))) {
-                        const int o = 32 + 2 * (p - K + 1);  // bit offset of base p-K+1 in [ch | C]
-                        const int word = o >> 5, sh = o & 31;
-                        uint32_t x;
-                        if (sh == 0) x = v[word];
-                        else if (word == 4) x = v[4] >> sh;  // the last pair ends exactly at bit 160
-                        else x = vkl::alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
-                        emit_pair(x, ok[g], 4 * j);
+                    for (int h = 0; h < 2; ++h) {
+                        uint32_t x[4], f[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int p = 16 * g + 8 * h + 2 * j;    // windows ending at p and p + 1
+                            const int o = 32 + 2 * (p - K + 1);      // bit offset of base p-K+1 in [ch | C]
+                            const int word = o >> 5, sh = o & 31;
+                            if (sh == 0) x[j] = v[word];
+                            else if (word == 4) x[j] = v[4] >> sh;   // the last pair ends exactly at bit 160
+                            else x[j] = vkl::alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
+                            f[j] = both & (1u << (16 * h + 4 * j));
+                        }
+                        const uint32_t full = append4(x, f);
+                        if (full) {  // rare: the queue was full, count the pair directly
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (full & (1u << j)) {
+                                    count_direct(x[j]);
+                                    count_direct(x[j] >> 2);
+                                }
+                        }
                     }
+                    // singles: at most a few per lane and piece
+                    uint32_t rem = one;
+                    while (__any(rem != 0u)) {
+                        if (rem != 0u) {
+                            const uint32_t b = vkl::ffbl(rem);                 // 4j
+                            rem &= rem - 1u;
+                            const uint32_t second = ((ok[g] >> b) & 1u) ^ 1u;  // 0: the window ending at p counts, 1: at p + 1
+                            // bit offset of the window's first base, relative to v[g]: p = 8g.. in this dword
+                            const uint32_t o = 32u + b + 2u * second - 2u * (K - 1);
+                            const uint32_t lo = o < 32u ? v[g] : v[g + 1];
+                            const uint32_t hi = o < 32u ? v[g + 1] : (g + 2 < 5 ? v[g + 2 < 5 ? g + 2 : 4] : 0u);  // (g = 3: the field ends with v[4])
+                            single(vkl::alignbit(hi, lo, o & 31u));
+                        }
+                    }
+                    // inside a piece only a queue that is filling up fast is drained (skewed bases): one check, half way
+#ifdef VK_BUCKET_DRAIN_EVERY_GROUP
+                    maybe_drain(kDrainAt);
+#else
+                    if (g == 1) maybe_drain(kDrainAt);
+#endif
                 }
-                if (g == 3) after_group();  // 64 positions of every lane done: drain the queues that hold a block
             }
         };
         SubWave sw = {0, 0, 0, 0};
@@ -807,71 +913,139 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_kernel(
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB, 1>(sbase, len, wr.w0, wr.w1, &scratch[wave][0], below, above, lane, win, ph_start, ph_end, sw);
+        wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
+                                                piece_start, ph_start, ph_end, sw);
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
-        // final drain: pad the last partial block of every queue, write it, then the rest of every run
+        if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
+        if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
+        // the end of the range: full blocks to the arena, the rest of every queue counted directly, runs closed
         wave_lds_fence();
-        uint32_t n = qcnt[wave][q] >> 1;
-        if (n > kQueueCap) n = kQueueCap;
-        const uint32_t nb = (n + kBlockEntries - 1) / kBlockEntries;
-        for (uint32_t e = n + sub; e < nb * kBlockEntries; e += 4) q16[q * kQueueCap + e] = 0xFFFFu;
-        wave_lds_fence();
-        drain_all(nb * kBlockEntries, nb);
-        const uint32_t left = runleft[wave][q], base = runbase[wave][q];
-        const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        for (uint32_t b = 0; b < left; ++b) {
-            gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u] = ff;
-            gq[static_cast<uint64_t>(base + b) * 8u + sub * 2u + 1u] = ff;
-        }
+        uint32_t n = qcnt[q];
+        if (n > kQueueBytes) n = kQueueBytes;
+        drain_all(n, n / kBlockBytes);
+        n = qcnt[q];
+        const uint16_t* q16 = reinterpret_cast<const uint16_t*>(qdata);
+        for (uint32_t i = sub; i < n / 2u; i += 4u) count_entry_direct<K>(hist_s, q, q16[i]);
+        const uint32_t used = qused[q];
+        if (sub == 0 && used <= kRunBlocks && used != 0u) hdrs[qrun[q]] = 0x80000000u | (used << 8) | q;
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 }
 
-// Pass B: one workgroup per (sample, queue) replays the bucket stream into LDS and adds the
-// 4^K/16 counters to the histogram (which already holds pass A's direct counts).
+// Pass B: one workgroup per (sample, bucket) replays the runs of its bucket into a 2 x 4^K/16-bin
+// LDS histogram and stores it, as it stands, to bucket_hist (plain coalesced stores).
+// Pass C (vk_bucket_merge_kernel): one thread per k-mer code adds the two counters that can name it
+// -- the code seen as the first and as the second window of a pair -- to the histogram, which already
+// holds pass A's direct counts.  (Adding from pass B with atomics in code order scattered every
+// lane to its own cache line: the bucket number is the END of the first window, the least
+// significant digits of its code; that flush alone took as long as the replay.)
 template <int K>
-__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp,
-                                                                         uint32_t* __restrict__ hist_out) {
-    constexpr uint32_t NCODE = 1u << (2 * K);
+__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp) {
     constexpr uint32_t LB = 2 * K - 4;
-    constexpr uint32_t BINS = 2u << LB;  // indexed by the entry: type bit | rest
+    constexpr uint32_t BINS = 2u << LB;  // type bit | index
+    constexpr uint32_t kList = 4096;     // runs listed per round (a uniform sample has ~2400 per bucket)
     __shared__ uint32_t hist[BINS];
+    __shared__ uint32_t list[kList];
+    __shared__ uint32_t nlist;
     const uint32_t s = blockIdx.x / kQueues, q = blockIdx.x % kQueues;
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
-    __syncthreads();
-    uint32_t nblk = bp.cursors[s * kQueues + q];
-    if (nblk > bp.cap_blocks) nblk = bp.cap_blocks;
-    const uint4* src = reinterpret_cast<const uint4*>(bp.buckets + (static_cast<uint64_t>(s) * kQueues + q) *
-                                                                       bp.cap_blocks * 32u);
-    const uint64_t n16 = static_cast<uint64_t>(nblk) * 8u;  // 16-byte groups
-    auto tally = [&](const uint4& v) __attribute__((always_inline)) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
-            if (lo != 0xFFFFu) atomicAdd(&hist[lo], 1u);
-            if (hi != 0xFFFFu) atomicAdd(&hist[hi + (1u << LB)], 1u);  // the high half holds the type-1 entries
-        }
+    uint32_t nruns = bp.cursors[s];
+    if (nruns > bp.runs_cap) nruns = bp.runs_cap;
+    const uint32_t* hdrs = bp.hdrs + static_cast<uint64_t>(s) * bp.runs_cap;
+    const uint8_t* arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
+    // Entry e = rest | last << LB (LB + 2 bits, garbage above for K = 8).  Type 0 counts under rest, type 1
+    // under (rest >> 2) | last << (LB - 2) = e >> 2: as BYTE offsets into the two halves of hist,
+    // (e << 2) & M and e & M with M = the LB + 2 bit mask without its two lowest bits.
+    constexpr uint32_t M = (1u << (LB + 2)) - 4u;
+    uint8_t* const h0 = reinterpret_cast<uint8_t*>(hist);
+    uint8_t* const h1 = reinterpret_cast<uint8_t*>(hist + (1u << LB));
+    auto tally2 = [&](uint32_t w) __attribute__((always_inline)) {  // two entries: the halves of a dword
+        atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w << 2) & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(h1 + (w & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w >> 14) & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(h1 + ((w >> 16) & M)), 1u);
     };
-    // four 16-byte loads in flight per thread: the stream is read once, latency is all there is to hide
-    uint64_t i = tid;
-    for (; i + 3ull * kCountThreads < n16; i += 4ull * kCountThreads) {
-        const uint4 v0 = src[i], v1 = src[i + kCountThreads], v2 = src[i + 2ull * kCountThreads],
-                    v3 = src[i + 3ull * kCountThreads];
-        tally(v0);
-        tally(v1);
-        tally(v2);
-        tally(v3);
+    const uint32_t g = tid & 255u;   // 256 threads per run: the 16-byte granule this thread reads (four per block)
+    const uint32_t grp = tid >> 8;   // four runs at a time
+    auto fetch = [&](uint32_t i, uint32_t n, uint4& v) __attribute__((always_inline)) -> bool {
+        const uint32_t item = i < n ? list[i] : 0u;
+        const bool have = i < n && (g >> 2) < (item >> 24);
+        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
+        return have;
+    };
+    auto tally4 = [&](const uint4& v) __attribute__((always_inline)) {
+        tally2(v.x);
+        tally2(v.y);
+        tally2(v.z);
+        tally2(v.w);
+    };
+    uint32_t r0 = 0;
+    while (r0 < nruns) {
+        // round: list this bucket's runs among the headers from r0 on, until the list is full
+        if (tid == 0) nlist = 0u;
+        __syncthreads();
+        uint32_t listed = 0;  // nlist as of the last barrier: the same in every thread, so the exit is uniform
+        for (; r0 < nruns; r0 += kCountThreads) {
+            if (listed + kCountThreads > kList) break;
+            const uint32_t r = r0 + tid;
+            const uint32_t h = r < nruns ? hdrs[r] : 0u;
+            // compacted per wave: one LDS atomic per wavefront, not one per run
+            const bool mine = (h >> 31) != 0u && (h & 0xFFu) == q;
+            const unsigned long long bal = __ballot(mine);
+            uint32_t base = 0;
+            if ((tid & 63u) == 0u && bal != 0ull) base = atomicAdd(&nlist, static_cast<uint32_t>(__popcll(bal)));
+            base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+            if (mine) list[base + __popcll(bal & ((1ull << (tid & 63u)) - 1ull))] = r | ((h >> 8) & 0xFFu) << 24;
+            __syncthreads();
+            listed = nlist;
+            __syncthreads();  // nobody adds to nlist before everybody has read it
+        }
+        const uint32_t n = listed;
+        // the stream is read once: keep eight 16-byte loads in flight per thread (two batches of four
+        // runs, the next batch's loads issued before the current one is tallied)
+        uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+        bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
+        uint32_t i = grp;
+        ha0 = fetch(i, n, a0); ha1 = fetch(i + 4, n, a1); ha2 = fetch(i + 8, n, a2); ha3 = fetch(i + 12, n, a3);
+        while (i < n) {
+            hb0 = fetch(i + 16, n, b0); hb1 = fetch(i + 20, n, b1); hb2 = fetch(i + 24, n, b2); hb3 = fetch(i + 28, n, b3);
+            if (ha0) tally4(a0);
+            if (ha1) tally4(a1);
+            if (ha2) tally4(a2);
+            if (ha3) tally4(a3);
+            i += 16;
+            if (i >= n) break;
+            ha0 = fetch(i + 16, n, a0); ha1 = fetch(i + 20, n, a1); ha2 = fetch(i + 24, n, a2); ha3 = fetch(i + 28, n, a3);
+            if (hb0) tally4(b0);
+            if (hb1) tally4(b1);
+            if (hb2) tally4(b2);
+            if (hb3) tally4(b3);
+            i += 16;
+        }
+        __syncthreads();
     }
-    for (; i < n16; i += kCountThreads) tally(src[i]);
     __syncthreads();
+    uint32_t* out = bp.bucket_hist + (static_cast<uint64_t>(s) * kQueues + q) * BINS;
+    for (uint32_t i = tid; i < BINS; i += kCountThreads) out[i] = hist[i];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void vk_bucket_merge_kernel(BucketParams bp, uint32_t* __restrict__ hist_out) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t LB = 2 * K - 4;
+    constexpr uint32_t BINS = 2u << LB;
+    const uint32_t s = blockIdx.x / (NCODE / 256), code = (blockIdx.x % (NCODE / 256)) * 256 + threadIdx.x;
+    const uint32_t raw = pair_reverse(code, K);  // first base least significant, as the pair entries are built
+    // as the FIRST window of a pair: bucket = its last two bases, counted under its first K - 2 bases
+    const uint32_t q0 = raw >> LB, i0 = raw & ((1u << LB) - 1u);
+    // as the SECOND window: bucket = bases K-3, K-2; counted under (first K - 3 bases | last base << (LB - 2))
+    const uint32_t q1 = (raw >> (LB - 2)) & 15u;
+    const uint32_t i1 = (raw & ((1u << (LB - 2)) - 1u)) | ((raw >> (2 * K - 2)) << (LB - 2));
+    const uint32_t* bh = bp.bucket_hist + static_cast<uint64_t>(s) * kQueues * BINS;
+    const uint32_t add = bh[q0 * BINS + i0] + bh[q1 * BINS + (1u << LB) + i1];
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
-    for (uint32_t i = tid; i < BINS; i += kCountThreads) {
-        const uint32_t v = hist[i];
-        // type-1 entries of this queue and type-0 entries of another can name the same code
-        if (v) atomicAdd(&out[pair_reverse(entry_raw<K>(q, i), K)], v);
-    }
+    out[code] += add;
 }
 
 // One thread per sample: the line phase each wave ended with must be the phase

@@ -21,9 +21,9 @@
 //     locally from the '@' / '+' framing, so byte ranges are independent;
 //   * k-mer windows are counted forward-strand only into an LDS histogram
 //     (ds_add_u32); the strand merge happens once per sample in K2;
-//   * 4^k u32 > LDS for k = 8, 9: windows are bucketed through wave-private LDS queues into
-//     16 streams per sample in HBM and replayed into 4^k/16-bin LDS histograms (vk_bucket_kernel,
-//     vk_bucket_count_kernel).
+//   * 4^k u32 > LDS for k = 8, 9: pairs of neighbouring windows are bucketed through wave-private LDS
+//     queues into 16 streams per sample in HBM (one byte per window) and replayed into 4^k/16-bin LDS
+//     histograms (vk_bucket_kernel, vk_bucket_count_kernel).
 //   vk_remap_kernel / vk_preprocess_kernel: `convert`'s remap and the input side of `query`.
 #include <hip/hip_runtime.h>
 
@@ -72,6 +72,7 @@ struct vk_ctx {
     uint8_t* d_img1 = nullptr;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
+    uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
 };
 
 #define VK_HIP(ctx, call)                     \
@@ -150,12 +151,15 @@ template <int K>
 int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
                  uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    // windows <= bytes/2; a uniform sample sends ~0.45*bytes/16 entries to each queue.  Room for
-    // bytes/16 entries (2.2x) plus the run each wave may leave unfinished.
-    uint64_t cap = maxlen / kQueues / kBlockEntries + 1 + static_cast<uint64_t>(parts) * kWaves * kRunBlocks;
-    cap = (cap + kRunBlocks - 1) / kRunBlocks * kRunBlocks;
-    if (cap > 0xFFFFFFFFull - kRunBlocks) return VK_EINVAL;
-    const size_t per_sample = static_cast<size_t>(kQueues) * cap * 128u;
+    // Arena of one sample, in 4 KiB runs: a pair entry is 2 bytes and a FASTQ holds at most len / 4
+    // pairs (sequence lines are less than half of the text), so len / 2 bytes however the pairs spread
+    // over the 16 buckets; plus the blocks a drain may leave unused at the end of a run (at most 3 of
+    // 64), plus one open run per (workgroup, wave, queue).
+    uint64_t runs = (maxlen / 2 + maxlen / 32) / kRunBytes + 16 + static_cast<uint64_t>(parts) * kWaves * kQueues;
+    if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
+    if (runs >= (1u << 24)) return VK_EINVAL;             // a run number travels in 24 bits (64 GiB of entries per sample)
+    constexpr size_t kBucketHistBytes = static_cast<size_t>(kQueues) * (2u << (2 * K - 4)) * sizeof(uint32_t);  // pass B -> merge
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + kBucketHistBytes;
     // never plan for more than three quarters of what is free (plus what this context already holds)
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -165,19 +169,24 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     uint32_t batch = static_cast<uint32_t>(budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
-    const size_t cursor_bytes = (static_cast<size_t>(batch) * kQueues * sizeof(uint32_t) + 255) / 256 * 256;
-    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap, cursor_bytes + batch * per_sample);
+    // workspace: cursors[batch] | hdrs[batch][runs] | bucket histograms[batch][16][2 * 4^K / 16] | arena[batch][runs][4 KiB]
+    const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs)) * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t bh_bytes = static_cast<size_t>(batch) * kBucketHistBytes;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap,
+                    head_bytes + bh_bytes + static_cast<size_t>(batch) * runs * kRunBytes);
     if (rc) return rc;
     BucketParams bp;
     bp.cursors = ctx->d_spill;
-    bp.buckets = ctx->d_spill + cursor_bytes / sizeof(uint32_t);
-    bp.cap_blocks = static_cast<uint32_t>(cap);
+    bp.hdrs = ctx->d_spill + batch;
+    bp.bucket_hist = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes);
+    bp.arena = reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes + bh_bytes;
+    bp.runs_cap = static_cast<uint32_t>(runs);
     VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
     ctx->last_block = kCountThreads;
-    ctx->last_lds = kWaves * 64 + 2 * 66 * 16 + kWaves * kQueues * kQueueCap * 2 + 3 * kWaves * kQueues * 4;
+    ctx->last_lds = kLdsBucketBytes;
     for (uint32_t s0 = 0; s0 < nsamples; s0 += batch) {
         const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
-        VK_HIP(ctx, hipMemsetAsync(bp.cursors, 0, static_cast<size_t>(n) * kQueues * sizeof(uint32_t), ctx->stream));
+        VK_HIP(ctx, hipMemsetAsync(ctx->d_spill, 0, head_bytes, ctx->stream));  // cursors and run headers
         ctx->last_grid = n * parts;
         if (sub) {
             SubParams sp = *sub;  // this sub-batch's slice of the per-sample arrays
@@ -193,7 +202,9 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, SubParams{});
         }
         VK_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp,
+        hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp);
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((vk_bucket_merge_kernel<K>), dim3(n * (NCODE / 256)), dim3(256), 0, ctx->stream, bp,
                            d_hist + static_cast<size_t>(s0) * NCODE);
         VK_HIP(ctx, hipGetLastError());
     }
@@ -201,11 +212,26 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
 }
 
 uint32_t choose_parts(uint32_t nsamples, uint64_t maxlen) {
-    // enough workgroups to fill 256 CUs a few times over, but never ranges so
-    // small that the per-wave phase sync dominates
-    uint32_t parts = 1;
-    while (static_cast<uint64_t>(nsamples) * parts < 512 && (maxlen / (parts * 2)) >= (1u << 20)) parts *= 2;
-    return parts;
+    // The count kernels keep two workgroups per CU resident: 512 slots on the 256 CUs.  A launch of
+    // G equal workgroups runs in ceil(G / 512) rounds, so G just below a multiple of 512 wastes the
+    // least (100 samples: 5 parts = 500 workgroups, not 8 = 800 in two rounds).  Parts never get so
+    // small (< 1 MiB) that the per-wave range sync shows, and a batch that fills the chip several
+    // times over anyway is left alone.
+    constexpr uint64_t kSlots = 512;
+    if (nsamples >= 4 * kSlots) return 1;
+    uint32_t best = 1;
+    double best_eff = 0.0;
+    for (uint32_t parts = 1; parts <= 512; ++parts) {
+        if (parts > 1 && maxlen / parts < (1u << 20)) break;
+        const uint64_t g = static_cast<uint64_t>(nsamples) * parts;
+        const double eff = static_cast<double>(g) / static_cast<double>((g + kSlots - 1) / kSlots * kSlots);
+        if (eff > best_eff) {
+            best_eff = eff;
+            best = parts;
+        }
+        if (eff >= 0.95) break;  // good enough: more parts only add range syncs, flushes and open runs
+    }
+    return best;
 }
 
 }  // namespace
@@ -242,6 +268,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
     {
         const char* e = getenv("VKIMG_IMAGE_SORT_ONLY");
         ctx->image_sort_only = e && e[0] == '1';
+        const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
+        if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
     }
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return VK_EHIP; }
     if (!own_stream) {

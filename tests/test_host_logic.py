@@ -174,3 +174,53 @@ def test_file_pipeline_batches_and_overlaps_without_a_gpu(tmp_path):
         want = oracle.fastq_to_image(synth.sample_fastq(i, 200, 150), 5, lut, 1024)[0].reshape(32, 32)
         im = Image.open(tmp_path / "out" / f"s{i}@00000030K+cgr+k5.png")
         assert np.array_equal(np.array(im), want) and im.info["varkoderMapping"] == "cgr"
+
+
+def test_basefrequency_sd_equals_reference_cases(tmp_path):
+    """image.get_basefrequency_sd against values the reference's own function returned for the same
+    fastp-style reports (tests/golden/basesd_cases.json, made by oracle/gen_golden_basesd.py)."""
+    import json
+    import os
+
+    from varkoder_amd import image
+    from varkoder_amd.config import QUAL_THRESH
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "basesd_cases.json")))
+    for name, js in gold["reports"].items():
+        (tmp_path / name).write_text(json.dumps(js))
+    for case in gold["cases"]:
+        got = image.get_basefrequency_sd([tmp_path / n for n in case["files"]])
+        assert got == pytest.approx(case["base_sd"], rel=1e-12, abs=0), case["files"]
+    assert gold["empty_list_returns"] is None and image.get_basefrequency_sd([]) == 0.0   # documented divergence
+    # the table the CLI builds from <intermediate>/clean_reads, and the flag it feeds
+    cr = tmp_path / "clean_reads"
+    cr.mkdir()
+    (cr / "good_fastp_unpaired.json").write_text(json.dumps(gold["reports"]["merged_only.json"]))
+    (cr / "poor_fastp_paired.json").write_text(json.dumps(gold["reports"]["low_quality.json"]))
+    tab = image.base_sd_table(cr, ["good", "poor", "absent"])
+    assert tab["good"] < QUAL_THRESH < tab["poor"] and tab["absent"] == 0.0
+    assert image.base_sd_table(tmp_path / "nowhere", ["good"]) == {}
+
+
+def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
+    """ImageEngine.stage_files marks a corrupt .gz or a vanished file as an empty sample instead of
+    raising out of the stager thread (the reference skips such a file and carries on)."""
+    import gzip
+
+    import torch
+    from varkoder_amd import synth
+    from varkoder_amd.engine import ImageEngine
+    good = synth.sample_fastq(3, 50, 150).tobytes()
+    (tmp_path / "a.fq").write_bytes(good)
+    with gzip.open(tmp_path / "b.fq.gz", "wb") as f:
+        f.write(good)
+    (tmp_path / "c.fq.gz").write_bytes(b"\x1f\x8b\x08\x00 this is not a gzip stream")
+    eng = ImageEngine.__new__(ImageEngine)          # no GPU here: only the host half is exercised
+    eng.device = 0
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    real_empty = torch.empty
+    monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "pin_memory"}))
+    pinned, total, offs, lens = eng.stage_files([tmp_path / "a.fq", tmp_path / "b.fq.gz", tmp_path / "c.fq.gz",
+                                                 tmp_path / "gone.fq"])
+    assert lens.tolist() == [len(good), len(good), 0, 0]
+    host = pinned.numpy()
+    assert bytes(host[int(offs[1]):int(offs[1]) + len(good)]) == good and total % 16 == 0

@@ -230,15 +230,25 @@ def run_image_from_clean(args, outdir, rank, world, local_rank):
     # image.py:1017: str(row index) + str(random integer), one draw per sample in row order
     seeds = {s: int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63) for i, s in enumerate(samples)}
     labels = read_labels(args.labels_csv)
+    from .image import base_sd_table
+    base_sd = base_sd_table(src, samples)                                     # image.py:1094-1097
     eprint("Subsampling, counting kmers and creating images for", len(files), "samples")
     per_sample = clean_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping,
                                  min_bp=parse_size(args.min_bp), max_bp=max_bp, seeds=seeds, labels=labels,
+                                 base_sd=base_sd,
                                  device=local_rank, rank=rank, world=world, io_threads=max(1, args.n_threads) * 4,
                                  verbose=args.verbose)
+    for s, v in per_sample.items():
+        v["base_frequencies_sd"] = base_sd.get(s, 0)
     merged = gather_stats(per_sample)
     if rank == 0:
         rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
         pd.DataFrame(rows).to_csv(args.stats_file, index=False)
+        if args.label_table:                                                  # image.py:1172-1185
+            lt = pd.DataFrame({"sample": samples,
+                               "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
+                               "possible_low_quality": [base_sd.get(s, 0) > QUAL_THRESH for s in samples]})
+            lt.to_csv(outdir / "labels.csv", index=False)
         eprint("All images done, saved in", str(outdir))
     if world > 1:
         import torch.distributed as dist
@@ -257,14 +267,19 @@ def run_image(args):
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)        # control plane only
     outdir = Path(args.outdir)
+    refuse = [False]
     if rank == 0:
-        if not args.overwrite and outdir.exists():                          # image.py:1219-1223
-            raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
-        if outdir.is_dir():
-            shutil.rmtree(outdir)
-        outdir.mkdir(parents=True)
+        refuse[0] = (not args.overwrite) and outdir.exists()                # image.py:1219-1223
+        if not refuse[0]:
+            if outdir.is_dir():
+                shutil.rmtree(outdir)
+            outdir.mkdir(parents=True)
     if world > 1:
-        dist.barrier()
+        dist.broadcast_object_list(refuse, src=0)   # every rank learns the verdict: nobody is left in a barrier
+    if refuse[0]:
+        if world > 1:
+            dist.destroy_process_group()
+        raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
     if args.from_clean:
         return run_image_from_clean(args, outdir, rank, world, local_rank)
     src = Path(args.input)
@@ -277,13 +292,16 @@ def run_image(args):
     levels = math.floor(math.log(len(samples) / 1000, 16)) if samples else 0  # image.py:1246
     levels = max(levels, 0)
     labels = read_labels(args.labels_csv)
+    from .image import base_sd_table
+    # the fastp reports sit next to the split files in the intermediate folder (image.py:1094-1097)
+    base_sd = base_sd_table(src.parent / "clean_reads", samples)
     eprint("varkoder_amd")
     eprint("Kmer size:", str(args.kmer_size))
     eprint("Counting kmers and creating images for", len(files), "files of", len(samples), "samples")
     if args.no_image:
         return
     per_file = fastqs_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping, labels=labels,
-                                overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
+                                base_sd=base_sd, overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
                                 world=world, io_threads=max(1, args.n_threads) * 4, verbose=args.verbose)
     # fold the per-file stats into per-sample stats like run_clean2img does (image.py:1057-1125)
     mine = defaultdict(OrderedDict)
@@ -294,6 +312,8 @@ def run_image(args):
             s[name] = s.get(name, 0) + st.get(name, 0)
         if "failed_step" in st:
             s["failed_step"] = st["failed_step"]
+    for name, st in mine.items():
+        st["base_frequencies_sd"] = base_sd.get(name, 0)
     merged = gather_stats(mine)
     if rank == 0:
         rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
@@ -301,7 +321,7 @@ def run_image(args):
         if args.label_table:
             lt = pd.DataFrame({"sample": samples,
                                "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
-                               "possible_low_quality": [0 > QUAL_THRESH for _ in samples]})
+                               "possible_low_quality": [base_sd.get(s, 0) > QUAL_THRESH for s in samples]})
             lt.to_csv(outdir / "labels.csv", index=False)
         eprint("All images done, saved in", str(outdir))
     if world > 1:

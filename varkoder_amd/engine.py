@@ -4,6 +4,7 @@ PyTorch is used for device memory and the stream only; every computation is a ca
 through the C ABI of include/vkimg.h.  There is no CPU fallback.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -109,20 +110,30 @@ class ImageEngine:
     def stage_files(self, paths, pool=None, slot=0):
         """Host half of upload_files: read the files into pinned staging buffer `slot` (kept and grown
         across calls).  Plain FASTQ files are read straight into it (parallel readinto, no
-        intermediate copy); gzip files are inflated first.  Touches no GPU state, so a pipeline can
-        stage the next batch on another thread while this one is copied and processed."""
+        intermediate copy); gzip files are inflated first.  May run on a thread of its own (a
+        pipeline stages the next batch while this one is copied and processed): the only GPU-runtime
+        call is the pinned allocation, made with this engine's device current.  A file that cannot
+        be read or inflated is staged with length 0 -- the caller sees an empty histogram for it and
+        skips it as the reference skips a file dsk fails on (commands/image.py:1070-1075) -- and
+        never takes the rest of the batch with it."""
         import gzip
         import os
+        import zlib
         torch = _torch()
+        torch.cuda.set_device(self.device)  # thread-local: a fresh thread would otherwise allocate on device 0
 
         def probe(p):
-            with open(p, "rb") as f:
-                gz = f.read(2) == b"\x1f\x8b"
-            if gz:
-                with gzip.open(p, "rb") as f:
-                    data = f.read()
-                return len(data), data
-            return os.path.getsize(p), None
+            try:
+                with open(p, "rb") as f:
+                    gz = f.read(2) == b"\x1f\x8b"
+                if gz:
+                    with gzip.open(p, "rb") as f:
+                        data = f.read()
+                    return len(data), data
+                return os.path.getsize(p), None
+            except (OSError, EOFError, zlib.error) as e:   # (gzip.BadGzipFile is an OSError)
+                print("cannot read", str(p) + ":", repr(e), file=sys.stderr)
+                return 0, None
         mapper = pool.map if pool is not None else map
         info = list(mapper(probe, paths))
         lens = np.array([n for n, _ in info], dtype=np.uint64)
@@ -143,11 +154,15 @@ class ImageEngine:
             o, n = int(offs[i]), int(lens[i])
             if info[i][1] is not None:
                 host[o:o + n] = np.frombuffer(info[i][1], dtype=np.uint8)
-            else:
-                with open(paths[i], "rb") as f:
-                    got = f.readinto(memoryview(host[o:o + n]))
-                if got != n:
-                    raise IOError(f"short read on {paths[i]}")
+            elif n:
+                try:
+                    with open(paths[i], "rb") as f:
+                        got = f.readinto(memoryview(host[o:o + n]))
+                except OSError as e:
+                    print("cannot read", str(paths[i]) + ":", repr(e), file=sys.stderr)
+                    got = -1
+                if got != n:      # unreadable or changed under us: an empty sample, not a dead batch
+                    lens[i] = 0
             host[o + n:(o + n + 15) // 16 * 16] = 0
         list(mapper(fill, range(len(paths))))
         host[pos:total] = 0

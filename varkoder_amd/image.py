@@ -42,6 +42,38 @@ def _engine(k, lut_key, lut=None, npix=None, device=0):
     return eng
 
 
+def get_basefrequency_sd(file_list):
+    """Quality figure the reference derives from fastp's JSON reports (commands/image.py:45-88): the
+    standard deviation of each base's frequency over read cycles 5..39, averaged over A, C, G, T and
+    over the report's `merged_and_filtered` / `read1_after_filtering` sections.  As in the reference
+    only the FIRST report of the list counts (its return statement sits inside the loop); where the
+    reference returns None for an empty list -- and then fails comparing it with the threshold --
+    this returns 0.0: no report, no flag."""
+    import json
+    for f in file_list:
+        with open(f, "r") as fh:
+            js = json.load(fh)
+        sds = []
+        for section in ("merged_and_filtered", "read1_after_filtering"):
+            try:
+                cur = js[section]["content_curves"]
+            except KeyError:
+                continue
+            rows = np.array([x for b, x in cur.items() if b in ("A", "T", "C", "G")])
+            sds.append(np.std(rows[:, 5:40], axis=1).mean())
+        return float(np.mean(sds)) if sds else float("nan")   # (the reference: np.mean([]) = nan)
+    return 0.0
+
+
+def base_sd_table(clean_reads_dir, samples):
+    """{sample: base-frequency sd} from `<sample>_fastp_*.json` in the intermediate clean_reads
+    folder (run_clean2img step E, commands/image.py:1094-1097); samples without a report get 0."""
+    d = Path(clean_reads_dir)
+    if not d.is_dir():
+        return {}
+    return {s: get_basefrequency_sd(sorted(d.glob(str(s) + "_fastp_*.json"))) for s in samples}
+
+
 def read_fastq_bytes(infile):
     """Whole FASTQ text of a plain or gzip-compressed file (dsk reads .gz natively)."""
     p = Path(infile)

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--dist", type=int, default=0, help="0 uniform, 1 GC-skew + homopolymers")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per sample (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the files -> PNGs measurement (N=1 only)")
+    ap.add_argument("--e2e-files", type=int, default=64)
+    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads per file of the end-to-end measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this "
                     "process may use: physical cores, capped by affinity and the cgroup's CPU quota)")
@@ -146,6 +149,74 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     ref = dsk_reference(bufs[0], args, cores)
     if ref:
         out["dsk"] = ref
+    return out
+
+
+def end_to_end(eng, args):
+    """SURVEY 8d's second timing: real files on disk -> PNG files on disk through the file pipeline
+    (parallel reads into a pinned buffer, one H2D DMA per batch, kernels, PNG encode), once for plain
+    FASTQ text and once for the .fq.gz files step C of the reference really hands over
+    (commands/image.py:696-708).  Files come from the synthetic generator (written here, outside the
+    timed region, and read back from the page cache)."""
+    import shutil
+    import tempfile
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+
+    import torch
+    from varkoder_amd import pipeline
+    nfiles, reads = args.e2e_files, args.e2e_reads
+    threads = cpu_budget()["usable_cores"]
+    tmp = Path(tempfile.mkdtemp(prefix="vk_e2e_"))
+    out = {"files": nfiles, "reads_per_file": reads, "read_len": args.readlen, "io_threads": threads}
+    try:
+        fq, offs, lens = eng.synth(1 << 20, nfiles, reads, args.readlen, dist=args.dist)
+        host = fq.cpu().numpy()
+        del fq
+        kb = reads * args.readlen // 1000
+        plain = [tmp / f"s{i:04d}@{kb:08d}K.fq" for i in range(nfiles)]
+        gz = [tmp / "gz" / f"s{i:04d}@{kb:08d}K.fq.gz" for i in range(nfiles)]
+        (tmp / "gz").mkdir()
+
+        def write(i):
+            blob = host[int(offs[i]):int(offs[i]) + int(lens[i])]
+            blob.tofile(plain[i])
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)       # gzip container, fast level
+            with open(gz[i], "wb") as f:
+                f.write(co.compress(blob.tobytes()) + co.flush())
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(write, range(nfiles)))
+        text_bytes = int(sum(int(x) for x in lens))
+        gz_bytes = sum(p.stat().st_size for p in gz)
+        del host
+        bases = nfiles * reads * args.readlen
+        for name, files, moved in (("plain_text", plain, text_bytes), ("fq_gz", gz, gz_bytes)):
+            dst = tmp / ("img_" + name)
+            pipeline.fastqs_to_images(files[:2], tmp / ("warm_" + name), k=args.k, mapping_code=args.mapping,
+                                      io_threads=threads, engine=eng)
+            t0 = time.perf_counter()
+            stats = pipeline.fastqs_to_images(files, dst, k=args.k, mapping_code=args.mapping, io_threads=threads,
+                                              engine=eng, batch_bytes=2 << 30)
+            dt = time.perf_counter() - t0
+            ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
+            out[name] = {"seconds": dt, "gbases_per_s": bases / dt / 1e9, "files_per_s": nfiles / dt,
+                         "file_bytes": moved, "file_gb_per_s": moved / dt / 1e9, "text_gb_per_s": text_bytes / dt / 1e9,
+                         "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png")))}
+        # the link itself, for scale: one pinned 1 GiB buffer, host to device
+        pin = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+        dev = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            dev.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        out["pcie_h2d_gb_per_s_pinned_1GiB"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+        out["note"] = ("files -> PNGs, page cache warm, one GPU; .fq.gz files are inflated on the host "
+                       "(zlib, io_threads threads) before the H2D copy")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -350,6 +421,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(eng, fastq, poffs, plens, args, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported side figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_e2e:
+            del hist, img           # make room: the end-to-end run allocates its own batches
+            try:
+                out["end_to_end"] = end_to_end(eng, args)
+            except Exception as e:  # a side measurement: never lose the bench line over it
+                out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

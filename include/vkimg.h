@@ -45,6 +45,13 @@ extern "C" {
 #define VK_EFORMAT 4     /* FASTQ framing inconsistent (per-sample status word) */
 #define VK_ENOMEM 5
 
+/* per-file status bits of vk_inflate_device */
+#define VK_GZ_BAD_HEADER 1u    /* not a gzip member (magic, method, reserved flags) */
+#define VK_GZ_BAD_DATA 2u      /* invalid DEFLATE data (block type, code set, distance too far back) */
+#define VK_GZ_TRUNCATED 4u     /* the stream ends before its last block / trailer */
+#define VK_GZ_OVERFLOW 8u      /* the text does not fit out_caps[i]: call again with more room */
+#define VK_GZ_BAD_SIZE 16u     /* a member's ISIZE differs from the bytes it inflated to */
+
 /* per-sample status bits written by the count stage */
 #define VK_ST_BAD_START 1u     /* first record malformed: no leading '@', or third line not '+' */
 #define VK_ST_BAD_PHASE 2u     /* line count mod 4 inconsistent between byte ranges / at EOF */
@@ -106,6 +113,17 @@ int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* o
                              const uint64_t* lengths, uint32_t nsamples, int k,
                              uint32_t parts_per_sample, uint32_t* d_hist,
                              uint32_t* d_status, uint8_t* d_img);
+
+/* Replaces the gzip reader inside dsk (`-file IN.fq.gz`, commands/image.py:771-790; the files are
+ * written by split_fastq, :696-708): inflates nfiles gzip files resident in HBM,
+ * d_gz[gz_offsets[i] .. +gz_lengths[i]), into d_out[out_offsets[i] ..), at most out_caps[i] bytes each
+ * (single-member files: the little-endian u32 in the file's last four bytes is the text length).
+ * Multi-member files and zero padding after the last member are accepted.  out_lengths[i] (host)
+ * receives the bytes written and status[i] (host) the VK_GZ_* bits; the call synchronises.
+ * Integrity: structure and ISIZE are checked, the CRC-32 of the trailer is not. */
+int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,
+                      uint32_t nfiles, void* d_out, const uint64_t* out_offsets, const uint64_t* out_caps,
+                      uint64_t* out_lengths, uint32_t* status);
 
 /* Host-buffer conveniences (one sample): H2D copy, kernels, D2H copy, sync.
  * vk_count_host returns VK_EFORMAT when the sample's status word is non-zero

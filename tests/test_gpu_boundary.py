@@ -197,7 +197,8 @@ def test_bench_script_runs_end_to_end(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5"],
+                          "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5", "--e2e-files", "6",
+                          "--e2e-reads", "5000"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -210,6 +211,10 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert "workload" in d["config"]
+    e = d["end_to_end"]
+    for leg in ("plain_text", "fq_gz"):
+        assert e[leg]["all_files_ok"] and e[leg]["pngs"] == 6 and e[leg]["gbases_per_s"] > 0
+    assert e["fq_gz"]["file_bytes"] < e["plain_text"]["file_bytes"]
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():

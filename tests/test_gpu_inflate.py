@@ -1,0 +1,129 @@
+"""vk_inflate_device (gzip inflate in HBM) against zlib / Python's gzip module on the host: the
+compressed files step D of the reference really receives (commands/image.py:696-708) must come out
+byte for byte."""
+import gzip
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from varkoder_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def gz(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+    return co.compress(data) + co.flush()
+
+
+def run(eng, files, caps=None):
+    import torch
+    offs, pos = [], 0
+    for f in files:
+        offs.append(pos)
+        pos += (len(f) + 15) // 16 * 16
+    host = np.zeros(pos + 16, dtype=np.uint8)
+    for o, f in zip(offs, files):
+        host[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    dev = torch.from_numpy(host).cuda()
+    if caps is None:
+        caps = [struct.unpack("<I", f[-4:])[0] if len(f) >= 4 else 0 for f in files]
+    ooffs, pos = [], 0
+    for c in caps:
+        ooffs.append(pos)
+        pos += (c + 15) // 16 * 16
+    out = torch.full((pos + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+    lens, status = eng.inflate(dev, np.array(offs, dtype=np.uint64), np.array([len(f) for f in files], dtype=np.uint64),
+                               out, np.array(ooffs, dtype=np.uint64), np.array(caps, dtype=np.uint64))
+    res = out.cpu().numpy()
+    return [bytes(res[o:o + int(n)]) for o, n in zip(ooffs, lens)], status, res, ooffs
+
+
+def test_inflate_matches_zlib_on_every_block_type(engines):
+    eng = engines(7)
+    rng = np.random.default_rng(5)
+    fq = synth.sample_fastq(3, 3000, 150, dist=1).tobytes()
+    noise = rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()
+    texts = {
+        "fastq_l1": (fq, 1), "fastq_l6": (fq, 6), "fastq_l9": (fq, 9), "stored_l0": (fq[:200000], 0),
+        "noise_l6": (noise, 6),                                   # incompressible: stored blocks inside a stream
+        "empty": (b"", 6), "one_byte": (b"A", 6), "rle": (b"G" * 100000, 9),
+        "period3": (b"ACG" * 40000, 6), "far_matches": (noise[:32768] + noise[:32768] + noise[100:32768], 9),
+        "text": (b"".join(b"line %d of some text\n" % i for i in range(20000)), 6),
+    }
+    names = list(texts)
+    files = [gz(*texts[n]) for n in names]
+    files.append(gz(fq[:50000], 6, zlib.Z_FIXED))                # fixed Huffman codes only
+    names.append("fixed")
+    texts["fixed"] = (fq[:50000], 6)
+    files.append(gz(fq, 6, zlib.Z_HUFFMAN_ONLY))                 # literals only, long codes
+    names.append("huffman_only")
+    texts["huffman_only"] = (fq, 6)
+    got, status, _, _ = run(eng, files)
+    for n, g, st in zip(names, got, status):
+        assert st == 0, (n, st)
+        assert g == texts[n][0], n
+
+
+def test_inflate_headers_members_and_padding(engines):
+    eng = engines(7)
+    a = synth.sample_fastq(1, 500, 150).tobytes()
+    b = synth.sample_fastq(2, 700, 100).tobytes()
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="sample@00001000K.fq", mode="wb", fileobj=buf, mtime=12345) as f:   # FNAME
+        f.write(a)
+    named = buf.getvalue()
+    # FEXTRA + FCOMMENT + FHCRC written by hand around a raw deflate stream
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(b) + raw.flush()
+    hdr = bytes([0x1f, 0x8b, 8, 4 | 16 | 2, 0, 0, 0, 0, 0, 3]) + struct.pack("<H", 6) + b"BC\x02\x00\x07\x00" + b"a comment\x00"
+    hdr += struct.pack("<H", zlib.crc32(hdr) & 0xFFFF)
+    fancy = hdr + body + struct.pack("<II", zlib.crc32(b), len(b))
+    multi = gz(a) + gz(b) + gz(b"") + gz(a[:1000])
+    padded = gz(a) + b"\x00" * 37
+    files = [named, fancy, multi, padded]
+    want = [a, b, a + b + a[:1000], a]
+    got, status, _, _ = run(eng, files, caps=[len(w) for w in want])
+    assert status.tolist() == [0, 0, 0, 0]
+    assert got == want
+    assert gzip.decompress(multi) == want[2] and gzip.decompress(padded) == a       # what the host tools make of them
+
+
+def test_inflate_flags_bad_streams_and_never_writes_past_its_slot(engines):
+    eng = engines(7)
+    a = synth.sample_fastq(4, 2000, 150).tobytes()
+    good = gz(a)
+    cut = good[: len(good) // 2]
+    flipped = bytearray(good)
+    for i in range(200, len(flipped) - 8, 97):
+        flipped[i] ^= 0x5A
+    notgz = b"@r1\nACGT\n+\nIIII\n" * 10
+    wrong_size = good[:-4] + struct.pack("<I", len(a) + 1)
+    files = [good, cut, bytes(flipped), notgz, wrong_size, good]
+    caps = [len(a), len(a), len(a), 64, len(a) + 16, len(a) // 3]          # the last one is too small on purpose
+    got, status, res, ooffs = run(eng, files, caps=caps)
+    assert status[0] == 0 and got[0] == a
+    assert status[1] & (_capi.VK_GZ_TRUNCATED | _capi.VK_GZ_BAD_DATA)
+    assert status[2] != 0
+    assert status[3] & _capi.VK_GZ_BAD_HEADER
+    assert status[4] & _capi.VK_GZ_BAD_SIZE
+    assert status[5] & _capi.VK_GZ_OVERFLOW
+    # nothing outside a file's own slot was touched: the filler between and after the slots is intact
+    for o, c, nxt in zip(ooffs, caps, ooffs[1:] + [res.size - 16]):
+        pad_from = o + c
+        assert (res[pad_from:nxt] == 0xEE).all()
+    assert (res[-16:] == 0xEE).all()
+
+
+def test_inflate_many_files_and_a_big_one(engines):
+    eng = engines(7)
+    big = synth.sample_fastq(9, 200000, 150).tobytes()            # 64 MB of text
+    files = [gz(big, 6)] + [gz(synth.sample_fastq(100 + i, 300 + 17 * i, 150, dist=i & 1).tobytes(), 1 + i % 9) for i in range(40)]
+    got, status, _, _ = run(eng, files)
+    assert not status.any()
+    assert got[0] == big
+    for i in range(40):
+        assert got[1 + i] == synth.sample_fastq(100 + i, 300 + 17 * i, 150, dist=i & 1).tobytes(), i

@@ -8,12 +8,13 @@ LIB_PATH = os.path.join(HERE, "libvkimg_hip.so")
 
 VK_OK, VK_EINVAL, VK_EHIP, VK_ENOMAP, VK_EFORMAT, VK_ENOMEM = 0, 1, 2, 3, 4, 5
 VK_ST_BAD_START, VK_ST_BAD_PHASE = 1, 2
+VK_GZ_BAD_HEADER, VK_GZ_BAD_DATA, VK_GZ_TRUNCATED, VK_GZ_OVERFLOW, VK_GZ_BAD_SIZE = 1, 2, 4, 8, 16
 
 # every symbol include/vkimg.h declares
 SYMBOLS = ("vk_abi_version", "vk_strerror", "vk_last_hip_error", "vk_ctx_create", "vk_ctx_destroy",
            "vk_ctx_sync", "vk_set_mapping", "vk_count_device", "vk_image_device",
            "vk_fastq_to_image_device", "vk_count_host", "vk_image_host", "vk_synth_fastq_device", "vk_remap_host", "vk_preprocess_device",
-           "vk_last_count_launch", "vk_count_sampled_device")
+           "vk_last_count_launch", "vk_count_sampled_device", "vk_inflate_device")
 
 _lib = None
 
@@ -53,10 +54,7 @@ def lib():
     L.vk_last_count_launch.argtypes = [vp, u32p, u32p, u32p]
     L.vk_preprocess_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, C.c_float, C.c_float, vp]
     L.vk_remap_host.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, vp, C.c_int, vp]
-    for name in SYMBOLS:
-        f = getattr(L, name)
-        if f.restype is C.c_int and name not in ("vk_abi_version",):
-            pass
+    L.vk_inflate_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, vp, u64p, u64p, u64p, u32p]
     _lib = L
     return L
 

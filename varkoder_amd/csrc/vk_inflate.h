@@ -1,0 +1,535 @@
+// vk_inflate.h -- gzip (RFC 1952 / DEFLATE RFC 1951) inflate on the GPU: step D's real inputs are
+// `<sample>@<bp>K.fq.gz` files (varKoder/commands/image.py:696-708), which dsk reads natively
+// (:771-790).  Here the compressed bytes cross PCIe and are inflated in HBM, straight into the
+// 16-byte aligned sample slots the count kernels read.
+// Part of the one translation unit vkimg.hip (device code for gfx950).
+//
+// One wavefront per gzip file.  A DEFLATE stream is a chain: the position of every token is known
+// only when the one before has been decoded.  The wave breaks that chain 64 bits at a time:
+//   * every lane decodes ONE whole token (literal | length + distance | end of block) as if it
+//     started at bit `pos + lane`: two table lookups in LDS and a few shifts, all 64 in parallel;
+//   * a short scalar walk follows the true chain through those 64 answers (lane 0's token, then the
+//     lane its end points to, ...) and collects the lanes on it: 6-10 tokens per step;
+//   * the tokens on the chain go to an LDS ring; when it fills up the whole wave resolves them:
+//     prefix sum of the lengths -> output offsets, literals stored by their lanes, matches copied
+//     from the text already written (L2: loads bypass the CU's L1) -- in rounds, because a match
+//     may read what an earlier token of the same batch writes; long matches are copied by all 64
+//     lanes at once.
+// Huffman tables: one lookup table per alphabet in LDS (11 bits for literal/length codes, 9 for
+// distances); the rare longer codes are finished bit by bit from the canonical first-code arrays.
+#ifndef VK_INFLATE_H
+#define VK_INFLATE_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace {
+
+constexpr int kLitRoot = 11, kDistRoot = 9;
+constexpr uint32_t kRing = 512;          // token ring (resolved when fewer than 64 slots are free)
+constexpr uint32_t kLongMatch = 24;      // matches at least this long are copied by the whole wave
+
+// table entry: bits 0-3 code length (0 = no such code, 15 = longer than the root: finish bit by bit),
+//              bits 4-7 extra bits, bits 8-9 kind (0 literal, 1 length, 2 end of block), bits 16-31 value
+constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindBad = 3;
+
+struct GzLds {
+    uint32_t lit[1 << kLitRoot];
+    uint32_t dst[1 << kDistRoot];
+    uint32_t ring[kRing];        // literal: byte; match: 0x80000000 | dist << 9 | len
+    uint16_t lit_sym[288];       // symbols ordered by (code length, symbol): canonical decoding of long codes
+    uint16_t dst_sym[32];
+    uint16_t lit_cnt[16], dst_cnt[16];
+    uint8_t lens[320];           // code lengths of the block being set up
+    uint8_t pre[128];            // code-length code: 7-bit lookup, sym | len << 5
+};
+
+__device__ __forceinline__ uint32_t gz_rev(uint32_t code, uint32_t len) { return __brev(code) >> (32u - len); }
+
+// 64 bits of the stream from bit position p (zero beyond the end of the input)
+__device__ __forceinline__ uint64_t gz_peek(const uint8_t* in, uint64_t nbytes, uint64_t p) {
+    const uint64_t b = p >> 3;
+    uint64_t lo = 0, hi = 0;
+    if (b + 16 <= nbytes) {
+        // two overlapping unaligned loads: bytes b..b+7 and b+8..b+15 (all lanes of a step share two lines)
+        __builtin_memcpy(&lo, in + b, 8);
+        __builtin_memcpy(&hi, in + b + 8, 8);
+    } else {
+        for (int i = 0; i < 8; ++i) {
+            if (b + i < nbytes) lo |= static_cast<uint64_t>(in[b + i]) << (8 * i);
+            if (b + 8 + i < nbytes) hi |= static_cast<uint64_t>(in[b + 8 + i]) << (8 * i);
+        }
+    }
+    const uint32_t s = static_cast<uint32_t>(p & 7u);
+    return s ? (lo >> s) | (hi << (64u - s)) : lo;
+}
+
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
+                                      67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
+                                       1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Build the lookup table of one alphabet from code lengths lens[0..n): returns false if the set is
+// over-subscribed, or incomplete (allowed only for a distance alphabet with at most one code, as zlib does).
+// Runs on the whole wave (lane = threadIdx.x & 63); lens, table, sym, cnt are in LDS.
+template <bool LITLEN>
+__device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint16_t* sym, uint16_t* cnt, int lane) {
+    constexpr int ROOT = LITLEN ? kLitRoot : kDistRoot;
+    // canonical codes: counts per length, first code per length (every lane computes the same scalars)
+    uint32_t count[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t l = lens[i];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) count[k] += (l == static_cast<uint32_t>(k)) ? 1u : 0u;
+    }
+    uint32_t used = 0;
+    int left = 1;
+    uint32_t first[16], offs[16];
+    first[0] = 0;
+    offs[0] = 0;
+    uint32_t code = 0, o = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        left = left * 2 - static_cast<int>(count[l]);
+        if (left < 0) return false;  // over-subscribed
+        code = (code + (l > 1 ? count[l - 1] : 0u)) << 1;
+        first[l] = code;
+        offs[l] = o;
+        o += count[l];
+        used += count[l];
+    }
+    if (left > 0 && (LITLEN || used > 1)) return false;  // incomplete
+    for (uint32_t i = lane; i < (1u << ROOT); i += 64) table[i] = kKindBad << 8;
+    if (lane < 16) cnt[lane] = static_cast<uint16_t>(lane ? count[lane] : 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // every symbol's rank among the symbols of its length = number of earlier symbols of that length
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const uint32_t l = s < n ? lens[s] : 0u;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < s0 + 64 && j < n; ++j) rank += (j < s && lens[j] == l) ? 1u : 0u;
+        if (l != 0u) {
+            uint32_t fl = 0, ol = 0;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                fl = l == static_cast<uint32_t>(k) ? first[k] : fl;
+                ol = l == static_cast<uint32_t>(k) ? offs[k] : ol;
+            }
+            sym[ol + rank] = static_cast<uint16_t>(s);
+            const uint32_t c = fl + rank;
+            uint32_t entry;
+            if (LITLEN) {
+                if (s < 256) entry = (s << 16) | (kKindLit << 8);
+                else if (s == 256) entry = kKindEob << 8;
+                else if (s < 286) entry = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
+                else entry = kKindBad << 8;  // 286, 287 never occur in valid data
+            } else {
+                entry = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
+                               : (kKindBad << 8);
+            }
+            if (l <= static_cast<uint32_t>(ROOT)) {
+                entry |= l;
+                for (uint32_t idx = gz_rev(c, l); idx < (1u << ROOT); idx += 1u << l) table[idx] = entry;
+            } else {
+                table[gz_rev(c, l) & ((1u << ROOT) - 1u)] = 15u | (kKindBad << 8);  // finish bit by bit
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// A code longer than the root, from the canonical arrays (bits arrive least significant first, codes
+// are defined most significant first: one bit at a time).  Returns the symbol, or 0xFFFF; len = its bits.
+__device__ __forceinline__ uint32_t gz_slow(uint64_t w, const uint16_t* cnt, const uint16_t* sym, uint32_t& len) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l < 16; ++l) {
+        code |= static_cast<uint32_t>(w >> (l - 1)) & 1u;
+        const uint32_t c = cnt[l];
+        if (code - first < c) {
+            len = l;
+            return sym[index + (code - first)];
+        }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
+    }
+    len = 15;
+    return 0xFFFFu;
+}
+
+// status bits of one gzip file
+constexpr uint32_t kGzBadHeader = 1u, kGzBadData = 2u, kGzTruncated = 4u, kGzOverflow = 8u, kGzBadSize = 16u;
+
+struct GzJob {
+    uint64_t in_off, in_len;     // compressed bytes in the input buffer
+    uint64_t out_off, out_cap;   // where the text goes, and how much room there is
+};
+
+__global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restrict__ gz, uint8_t* __restrict__ out,
+                                                         const GzJob* __restrict__ jobs, uint32_t njobs,
+                                                         unsigned long long* __restrict__ out_len,
+                                                         uint32_t* __restrict__ status) {
+    __shared__ GzLds L;
+    const uint32_t job = blockIdx.x;
+    if (job >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t* in = gz + jobs[job].in_off;
+    const uint64_t nbytes = jobs[job].in_len;
+    uint8_t* dst = out + jobs[job].out_off;
+    const uint64_t cap = jobs[job].out_cap;
+    const uint64_t nbits = nbytes * 8;
+
+    uint64_t pos = 0;      // bit position in the input (wave-uniform, like everything that steers the loops)
+    uint64_t opos = 0;     // bytes of text written
+    uint32_t st = 0;
+    uint32_t nring = 0;
+
+    // The ring's tokens -> text.  Output offsets by prefix sum; then rounds: the longest run of tokens
+    // whose sources are already written goes out in parallel, the stores are awaited, and so on.
+    uint64_t member_text0 = 0;  // text offset where the current member starts (distances cannot reach below it)
+    auto resolve = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ring was written by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        uint64_t base = opos;   // output offset of ring[t0]
+        for (uint32_t t0 = 0; t0 < nring && st == 0; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const uint32_t tok = t < nring ? L.ring[t] : 0u;
+            const bool live = t < nring;
+            const bool is_match = (tok >> 31) != 0u;
+            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
+            const uint32_t dist = (tok >> 9) & 0xFFFFu;
+            // inclusive prefix sum of len over the wave
+            uint32_t incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            const uint64_t off = base + (incl - len);  // where this lane's token starts
+            if (base + total > cap) { st |= kGzOverflow; break; }
+            // a distance beyond the text written so far (in this gzip member) is an error
+            const bool bad = live && is_match && (dist == 0u || dist > off - member_text0);
+            if (__any(bad)) { st |= kGzBadData; break; }
+            // source ends (exclusive) and rounds
+            const uint64_t src_end = is_match ? off - dist + (len < dist ? len : dist) : 0;
+            uint64_t frontier = base;          // everything below is written and visible
+            uint32_t done = 0;                 // tokens [0, done) of this group are out
+            const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
+            while (done < ngroup) {
+                const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
+                                   (!is_match || src_end <= frontier);
+                const unsigned long long rb = __ballot(ready);
+                // first lane >= done that is not ready
+                const unsigned long long notready = ~rb & (~0ull << done);
+                uint32_t upto = notready ? static_cast<uint32_t>(__builtin_ctzll(notready)) : 64u;
+                if (upto > ngroup) upto = ngroup;
+                const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
+                // short tokens: one lane each
+                if (mine && !is_match) {
+                    dst[off] = static_cast<uint8_t>(tok);
+                } else if (mine && len < kLongMatch) {
+                    const uint8_t* src = dst + (off - dist);
+                    for (uint32_t i = 0; i < len; ++i) {
+                        const uint8_t b = __hip_atomic_load(src + (i < dist ? i : i % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dst[off + i] = b;
+                    }
+                }
+                // long matches: the whole wave, one after the other (sources below the frontier: independent)
+                unsigned long long lb = __ballot(mine && is_match && len >= kLongMatch);
+                while (lb) {
+                    const int l = __builtin_ctzll(lb);
+                    lb &= lb - 1;
+                    const uint32_t mlen = __shfl(len, l), mdist = __shfl(dist, l);
+                    const uint32_t lo = __shfl(static_cast<uint32_t>(off), l), hi = __shfl(static_cast<uint32_t>(off >> 32), l);
+                    const uint64_t moff = (static_cast<uint64_t>(hi) << 32) | lo;
+                    const uint8_t* src = dst + (moff - mdist);
+                    for (uint32_t i = lane; i < mlen; i += 64) {
+                        const uint8_t b = __hip_atomic_load(src + (i < mdist ? i : i % mdist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        dst[moff + i] = b;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
+                done = upto;
+                frontier = upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total;  // start of the first token still to do
+            }
+            base += total;
+        }
+        opos = base;
+        nring = 0;
+    };
+
+    // ---- gzip members ---------------------------------------------------------------------------
+    bool any_member = false;
+    while (st == 0) {
+        // trailing zero padding after the last member is tolerated (as Python's gzip module does)
+        if (any_member) {
+            while ((pos >> 3) < nbytes && in[pos >> 3] == 0) pos += 8;
+            if ((pos >> 3) >= nbytes) break;
+        }
+        if ((pos >> 3) + 18 > nbytes) { st |= any_member ? kGzTruncated : kGzBadHeader; break; }
+        const uint8_t* h = in + (pos >> 3);
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) { st |= kGzBadHeader; break; }
+        const uint32_t flg = h[3];
+        uint64_t p = (pos >> 3) + 10;
+        if (flg & 4) {  // FEXTRA
+            if (p + 2 > nbytes) { st |= kGzTruncated; break; }
+            p += 2 + (static_cast<uint32_t>(in[p]) | (static_cast<uint32_t>(in[p + 1]) << 8));
+        }
+        if (flg & 8) {  // FNAME
+            while (p < nbytes && in[p] != 0) ++p;
+            ++p;
+        }
+        if (flg & 16) {  // FCOMMENT
+            while (p < nbytes && in[p] != 0) ++p;
+            ++p;
+        }
+        if (flg & 2) p += 2;  // FHCRC
+        if (p + 8 > nbytes) { st |= kGzTruncated; break; }
+        pos = p * 8;
+        any_member = true;
+        member_text0 = opos;
+
+        // ---- DEFLATE blocks ---------------------------------------------------------------------
+        bool last = false;
+        while (!last && st == 0) {
+            if (pos + 3 > nbits) { st |= kGzTruncated; break; }
+            uint64_t w = gz_peek(in, nbytes, pos);
+            last = (w & 1u) != 0u;
+            const uint32_t type = static_cast<uint32_t>(w >> 1) & 3u;
+            pos += 3;
+            if (type == 0) {  // stored
+                pos = (pos + 7) & ~7ull;
+                const uint64_t b = pos >> 3;
+                if (b + 4 > nbytes) { st |= kGzTruncated; break; }
+                const uint32_t len = in[b] | (static_cast<uint32_t>(in[b + 1]) << 8);
+                const uint32_t nlen = in[b + 2] | (static_cast<uint32_t>(in[b + 3]) << 8);
+                if ((len ^ nlen) != 0xFFFFu) { st |= kGzBadData; break; }
+                if (b + 4 + len > nbytes) { st |= kGzTruncated; break; }
+                resolve();
+                if (st) break;
+                if (opos + len > cap) { st |= kGzOverflow; break; }
+                for (uint32_t i = lane; i < len; i += 64) dst[opos + i] = in[b + 4 + i];
+                __builtin_amdgcn_s_waitcnt(0x0070);
+                opos += len;
+                pos = (b + 4 + len) * 8;
+                continue;
+            }
+            if (type == 3) { st |= kGzBadData; break; }
+            uint32_t nlit, ndist;
+            if (type == 1) {  // fixed codes
+                for (uint32_t i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                if (lane < 32) L.lens[288 + lane] = 5;
+                nlit = 288;
+                ndist = 32;  // 32 five-bit codes make the set complete; 30 and 31 never occur in valid data
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {  // dynamic codes
+                w = gz_peek(in, nbytes, pos);
+                nlit = (static_cast<uint32_t>(w) & 31u) + 257;
+                ndist = (static_cast<uint32_t>(w >> 5) & 31u) + 1;
+                const uint32_t ncode = (static_cast<uint32_t>(w >> 10) & 15u) + 4;
+                pos += 14;
+                if (nlit > 286 || ndist > 30) { st |= kGzBadData; break; }
+                // code-length code: 19 lengths of 3 bits in a fixed order
+                uint32_t pl[19];
+#pragma unroll
+                for (int i = 0; i < 19; ++i) pl[i] = 0;
+                w = gz_peek(in, nbytes, pos);
+                for (uint32_t i = 0; i < ncode; ++i) {
+                    const uint32_t v = static_cast<uint32_t>(w >> (3 * i)) & 7u;
+#pragma unroll
+                    for (int k = 0; k < 19; ++k) pl[k] = (kPreOrder[i] == k) ? v : pl[k];
+                }
+                pos += 3 * ncode;
+                // 7-bit lookup table for it (small: every lane computes all of it, lane 0 stores)
+                {
+                    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, first[8];
+#pragma unroll
+                    for (int k = 0; k < 19; ++k) {
+#pragma unroll
+                        for (int l = 1; l < 8; ++l) cnt[l] += pl[k] == static_cast<uint32_t>(l) ? 1u : 0u;
+                    }
+                    int left = 1;
+                    uint32_t code = 0;
+                    first[0] = 0;
+                    bool ok = true;
+#pragma unroll
+                    for (int l = 1; l < 8; ++l) {
+                        left = left * 2 - static_cast<int>(cnt[l]);
+                        if (left < 0) ok = false;
+                        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
+                        first[l] = code;
+                    }
+                    if (!ok || left > 0) { st |= kGzBadData; break; }
+                    for (uint32_t i = lane; i < 128; i += 64) L.pre[i] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        uint32_t next[8];
+#pragma unroll
+                        for (int l = 0; l < 8; ++l) next[l] = first[l];
+                        for (uint32_t s = 0; s < 19; ++s) {
+                            uint32_t l = 0;
+#pragma unroll
+                            for (int k = 0; k < 19; ++k) l = s == static_cast<uint32_t>(k) ? pl[k] : l;
+                            if (l == 0) continue;
+                            uint32_t c = 0;
+#pragma unroll
+                            for (int k = 1; k < 8; ++k) {
+                                if (l == static_cast<uint32_t>(k)) {
+                                    c = next[k];
+                                    next[k] = c + 1;
+                                }
+                            }
+                            for (uint32_t idx = gz_rev(c, l); idx < 128; idx += 1u << l) L.pre[idx] = static_cast<uint8_t>(s | (l << 5));
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // the nlit + ndist code lengths, run-length coded with the code-length code
+                uint32_t i = 0, prev = 0;
+                bool ok = true;
+                while (i < nlit + ndist) {
+                    if (pos > nbits) { ok = false; break; }
+                    w = gz_peek(in, nbytes, pos);
+                    const uint32_t e = L.pre[static_cast<uint32_t>(w) & 127u];
+                    const uint32_t l = e >> 5, s = e & 31u;
+                    if (l == 0) { ok = false; break; }
+                    pos += l;
+                    w >>= l;
+                    uint32_t rep = 1, val = s;
+                    if (s == 16) {
+                        if (i == 0) { ok = false; break; }
+                        rep = 3 + (static_cast<uint32_t>(w) & 3u);
+                        val = prev;
+                        pos += 2;
+                    } else if (s == 17) {
+                        rep = 3 + (static_cast<uint32_t>(w) & 7u);
+                        val = 0;
+                        pos += 3;
+                    } else if (s == 18) {
+                        rep = 11 + (static_cast<uint32_t>(w) & 127u);
+                        val = 0;
+                        pos += 7;
+                    }
+                    if (i + rep > nlit + ndist) { ok = false; break; }
+                    if (lane == 0)
+                        for (uint32_t r = 0; r < rep; ++r) L.lens[(i + r < nlit ? i + r : 288 + (i + r - nlit))] = static_cast<uint8_t>(val);
+                    i += rep;
+                    prev = val;
+                }
+                if (!ok) { st |= kGzBadData; break; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (L.lens[256] == 0) { st |= kGzBadData; break; }  // no end-of-block code
+            }
+            if (!gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) ||
+                !gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane)) {
+                st |= kGzBadData;
+                break;
+            }
+
+            // ---- tokens ---------------------------------------------------------------------
+            bool eob = false;
+            while (!eob && st == 0) {
+                if (pos >= nbits) { st |= kGzTruncated; break; }
+                if (nring + 64 > kRing) {
+                    resolve();
+                    if (st) break;
+                }
+                // every lane: the token that would start at pos + lane
+                const uint64_t ww = gz_peek(in, nbytes, pos + lane);
+                uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
+                uint32_t used = e & 15u;
+                if (used == 15u) {  // a long code (rare)
+                    uint32_t l;
+                    const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
+                    used = l;
+                    if (s < 256) e = (s << 16) | (kKindLit << 8);
+                    else if (s == 256) e = kKindEob << 8;
+                    else if (s < 286) e = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
+                    else e = kKindBad << 8;
+                }
+                uint32_t kind = (e >> 8) & 3u;
+                uint32_t tok = e >> 16;  // literal byte
+                if (kind == kKindLen) {
+                    const uint32_t xb = (e >> 4) & 15u;
+                    const uint32_t len = (e >> 16) + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
+                    used += xb;
+                    const uint64_t w2 = ww >> used;
+                    uint32_t d = L.dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
+                    uint32_t dl = d & 15u;
+                    if (dl == 15u) {
+                        uint32_t l;
+                        const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
+                        dl = l;
+                        d = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
+                                   : (kKindBad << 8);
+                    }
+                    if (((d >> 8) & 3u) != kKindLen || dl == 0u) {
+                        kind = kKindBad;
+                    } else {
+                        const uint32_t dxb = (d >> 4) & 15u;
+                        const uint32_t dist = (d >> 16) + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
+                        used += dl + dxb;
+                        tok = 0x80000000u | (dist << 9) | len;
+                    }
+                }
+                if (used == 0u) kind = kKindBad;
+                // the true chain through the 64 answers
+                unsigned long long chain = 0;
+                uint32_t at = 0, ntok = 0;
+                bool bad = false;
+                while (at < 64) {
+                    const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
+                    if (k == kKindBad) { bad = true; break; }
+                    const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
+                    if (k == kKindEob) {
+                        eob = true;
+                        at += u;
+                        break;
+                    }
+                    chain |= 1ull << at;
+                    ++ntok;
+                    at += u;
+                }
+                if (bad) { st |= kGzBadData; break; }
+                if ((chain >> lane) & 1ull)
+                    L.ring[nring + __popcll(chain & ((1ull << lane) - 1ull))] = tok;
+                nring += ntok;
+                pos += at;
+                if (pos > nbits) st |= kGzTruncated;  // the chain ran off the end of the file
+            }
+        }
+        if (st) break;
+        resolve();
+        if (st) break;
+        // trailer: CRC32 (not verified here) and ISIZE
+        pos = (pos + 7) & ~7ull;
+        const uint64_t b = pos >> 3;
+        if (b + 8 > nbytes) { st |= kGzTruncated; break; }
+        const uint32_t isize = in[b + 4] | (static_cast<uint32_t>(in[b + 5]) << 8) | (static_cast<uint32_t>(in[b + 6]) << 16) |
+                               (static_cast<uint32_t>(in[b + 7]) << 24);
+        if (isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }
+        pos = (b + 8) * 8;
+    }
+    if (lane == 0) {
+        out_len[job] = opos;
+        status[job] = st;
+    }
+}
+
+}  // namespace
+
+#endif  // VK_INFLATE_H

@@ -32,12 +32,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "vkimg.h"
 #include "vk_lane.h"
 
 #include "vk_count.h"
 #include "vk_image.h"
+#include "vk_inflate.h"
 #include "vk_aux.h"
 
 // ---------------------------------------------------------------- C ABI ------
@@ -64,6 +66,8 @@ struct vk_ctx {
     size_t spill_budget = 96ull << 30;  // bytes of HBM the spill path may use at a time
     // host-call staging
     uint64_t* d_sub = nullptr;    // subsampling launches: seeds | thresholds
+    uint8_t* d_gzjobs = nullptr;  // vk_inflate_device: jobs | text lengths | status words
+    size_t gzjobs_cap = 0;
     size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
@@ -288,7 +292,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -468,6 +472,32 @@ int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img) {
     if (rc) return rc;
     VK_HIP(ctx, hipMemcpyAsync(img, ctx->d_img1, ctx->npix[k], hipMemcpyDeviceToHost, ctx->stream));
     VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VK_OK;
+}
+
+int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,
+                      uint32_t nfiles, void* d_out, const uint64_t* out_offsets, const uint64_t* out_caps,
+                      uint64_t* out_lengths, uint32_t* status) {
+    if (!ctx || !gz_offsets || !gz_lengths || !out_offsets || !out_caps || !out_lengths || !status) return VK_EINVAL;
+    if (nfiles == 0) return VK_OK;
+    if (!d_gz || !d_out) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t jobs_b = static_cast<size_t>(nfiles) * sizeof(GzJob), len_b = static_cast<size_t>(nfiles) * 8,
+                 st_b = static_cast<size_t>(nfiles) * 4;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + st_b);
+    if (rc) return rc;
+    std::vector<GzJob> jobs(nfiles);
+    for (uint32_t i = 0; i < nfiles; ++i) jobs[i] = GzJob{gz_offsets[i], gz_lengths[i], out_offsets[i], out_caps[i]};
+    GzJob* d_jobs = reinterpret_cast<GzJob*>(ctx->d_gzjobs);
+    unsigned long long* d_len = reinterpret_cast<unsigned long long*>(ctx->d_gzjobs + jobs_b);
+    uint32_t* d_st = reinterpret_cast<uint32_t*>(ctx->d_gzjobs + jobs_b + len_b);
+    VK_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs_b, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(vk_inflate_kernel, dim3(nfiles), dim3(64), 0, ctx->stream, static_cast<const uint8_t*>(d_gz),
+                       static_cast<uint8_t*>(d_out), d_jobs, nfiles, d_len, d_st);
+    VK_HIP(ctx, hipGetLastError());
+    VK_HIP(ctx, hipMemcpyAsync(out_lengths, d_len, len_b, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(status, d_st, st_b, hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also keeps `jobs` alive until the copy has read it)
     return VK_OK;
 }
 

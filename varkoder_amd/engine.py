@@ -182,6 +182,23 @@ class ImageEngine:
         """Like upload() for files on disk (stage_files + upload_staged)."""
         return self.upload_staged(self.stage_files(paths, pool))
 
+    def inflate(self, gz, gz_offsets, gz_lengths, out, out_offsets, out_caps):
+        """gzip files resident in HBM -> FASTQ text in HBM (vk_inflate_device; dsk reads .gz natively,
+        commands/image.py:771-790).  gz, out: uint8 device tensors; offsets / lengths / caps: uint64
+        arrays.  Returns (text_lengths uint64[n], status uint32[n] of VK_GZ_* bits); synchronises."""
+        n = len(gz_offsets)
+        go, gl = self._desc(gz_offsets, gz_lengths)
+        oo, oc = self._desc(out_offsets, out_caps)
+        lens = np.zeros(n, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.uint32)
+        st = self.L.vk_inflate_device(self.ctx, self._ptr(gz), go.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      gl.ctypes.data_as(C.POINTER(C.c_uint64)), n, self._ptr(out),
+                                      oo.ctypes.data_as(C.POINTER(C.c_uint64)), oc.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      lens.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      status.ctypes.data_as(C.POINTER(C.c_uint32)))
+        _capi.check(self.ctx, st, "vk_inflate_device")
+        return lens, status
+
     # -- stages ----------------------------------------------------------------
     def count(self, fastq, offsets, lengths, parts=0, hist=None, status=None):
         """K1 (+check): forward-strand histograms int32/uint32 [n, 4^k] and status [n]."""

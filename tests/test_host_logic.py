@@ -202,8 +202,9 @@ def test_basefrequency_sd_equals_reference_cases(tmp_path):
 
 
 def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
-    """ImageEngine.stage_files marks a corrupt .gz or a vanished file as an empty sample instead of
-    raising out of the stager thread (the reference skips such a file and carries on)."""
+    """ImageEngine.stage_files reads files as they are on disk (gzip files stay compressed: they are
+    inflated on the GPU) and stages a vanished or empty one as an empty sample instead of raising out
+    of the stager thread (the reference skips such a file and carries on)."""
     import gzip
 
     import torch
@@ -213,14 +214,19 @@ def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
     (tmp_path / "a.fq").write_bytes(good)
     with gzip.open(tmp_path / "b.fq.gz", "wb") as f:
         f.write(good)
-    (tmp_path / "c.fq.gz").write_bytes(b"\x1f\x8b\x08\x00 this is not a gzip stream")
+    zbytes = (tmp_path / "b.fq.gz").read_bytes()
+    (tmp_path / "c.fq.gz").write_bytes(b"\x1f\x8b")           # too short to be a gzip member
     eng = ImageEngine.__new__(ImageEngine)          # no GPU here: only the host half is exercised
     eng.device = 0
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     real_empty = torch.empty
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "pin_memory"}))
-    pinned, total, offs, lens = eng.stage_files([tmp_path / "a.fq", tmp_path / "b.fq.gz", tmp_path / "c.fq.gz",
-                                                 tmp_path / "gone.fq"])
-    assert lens.tolist() == [len(good), len(good), 0, 0]
-    host = pinned.numpy()
-    assert bytes(host[int(offs[1]):int(offs[1]) + len(good)]) == good and total % 16 == 0
+    st = eng.stage_files([tmp_path / "b.fq.gz", tmp_path / "a.fq", tmp_path / "c.fq.gz", tmp_path / "gone.fq"])
+    assert st["is_gz"].tolist() == [True, False, True, False]
+    assert st["disk"].tolist() == [len(zbytes), len(good), 0, 0]
+    assert st["lens"].tolist() == [0, len(good), 0, 0]              # a gzip file's text length comes from the GPU
+    assert st["caps"].tolist() == [len(good), len(good), 0, 0]      # ... its slot from the ISIZE word
+    host = st["pinned"].numpy()
+    assert st["offs"][1] == 0 and bytes(host[:len(good)]) == good   # plain text first, at its final offset
+    assert st["src"][0] >= st["plain_total"] and bytes(host[int(st["src"][0]):int(st["src"][0]) + len(zbytes)]) == zbytes
+    assert st["offs"][0] >= st["plain_total"] and st["text_total"] % 16 == 0

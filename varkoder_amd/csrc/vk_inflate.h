@@ -166,6 +166,108 @@ __device__ __forceinline__ uint32_t gz_slow(uint64_t w, const uint16_t* cnt, con
     return 0xFFFFu;
 }
 
+// The header of a dynamic-codes block at bit `pos` (just behind the three block-type bits): HLIT, HDIST,
+// HCLEN, the code-length code, and the run-length coded code lengths, which go to L.lens (literal/length
+// codes at 0.., distance codes at 288..).  Advances pos; false if the header is not valid.
+__device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint64_t nbits, uint64_t& pos,
+                                  uint32_t& nlit, uint32_t& ndist, int lane) {
+    uint64_t w = gz_peek(in, nbytes, pos);
+    nlit = (static_cast<uint32_t>(w) & 31u) + 257;
+    ndist = (static_cast<uint32_t>(w >> 5) & 31u) + 1;
+    const uint32_t ncode = (static_cast<uint32_t>(w >> 10) & 15u) + 4;
+    pos += 14;
+    if (nlit > 286 || ndist > 30) return false;
+    // code-length code: ncode lengths of 3 bits in a fixed order
+    uint32_t pl[19];
+#pragma unroll
+    for (int i = 0; i < 19; ++i) pl[i] = 0;
+    w = gz_peek(in, nbytes, pos);
+    for (uint32_t i = 0; i < ncode; ++i) {
+        const uint32_t v = static_cast<uint32_t>(w >> (3 * i)) & 7u;
+#pragma unroll
+        for (int k = 0; k < 19; ++k) pl[k] = (kPreOrder[i] == k) ? v : pl[k];
+    }
+    pos += 3 * ncode;
+    // its 7-bit lookup table (small: every lane computes the codes, lane 0 stores)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, first[8];
+#pragma unroll
+    for (int k = 0; k < 19; ++k) {
+#pragma unroll
+        for (int l = 1; l < 8; ++l) cnt[l] += pl[k] == static_cast<uint32_t>(l) ? 1u : 0u;
+    }
+    int left = 1;
+    uint32_t code = 0;
+    first[0] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+        left = left * 2 - static_cast<int>(cnt[l]);
+        if (left < 0) ok = false;
+        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
+        first[l] = code;
+    }
+    if (!ok || left > 0) return false;
+    for (uint32_t i = lane; i < 128; i += 64) L.pre[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        uint32_t next[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) next[l] = first[l];
+        for (uint32_t s = 0; s < 19; ++s) {
+            uint32_t l = 0;
+#pragma unroll
+            for (int k = 0; k < 19; ++k) l = s == static_cast<uint32_t>(k) ? pl[k] : l;
+            if (l == 0) continue;
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                if (l == static_cast<uint32_t>(k)) {
+                    c = next[k];
+                    next[k] = c + 1;
+                }
+            }
+            for (uint32_t idx = gz_rev(c, l); idx < 128; idx += 1u << l) L.pre[idx] = static_cast<uint8_t>(s | (l << 5));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the nlit + ndist code lengths, run-length coded with the code-length code
+    uint32_t i = 0, prev = 0;
+    while (i < nlit + ndist) {
+        if (pos > nbits) return false;
+        w = gz_peek(in, nbytes, pos);
+        const uint32_t e = L.pre[static_cast<uint32_t>(w) & 127u];
+        const uint32_t l = e >> 5, s = e & 31u;
+        if (l == 0) return false;
+        pos += l;
+        w >>= l;
+        uint32_t rep = 1, val = s;
+        if (s == 16) {
+            if (i == 0) return false;
+            rep = 3 + (static_cast<uint32_t>(w) & 3u);
+            val = prev;
+            pos += 2;
+        } else if (s == 17) {
+            rep = 3 + (static_cast<uint32_t>(w) & 7u);
+            val = 0;
+            pos += 3;
+        } else if (s == 18) {
+            rep = 11 + (static_cast<uint32_t>(w) & 127u);
+            val = 0;
+            pos += 7;
+        }
+        if (i + rep > nlit + ndist) return false;
+        if (lane == 0)
+            for (uint32_t r = 0; r < rep; ++r) L.lens[(i + r < nlit ? i + r : 288 + (i + r - nlit))] = static_cast<uint8_t>(val);
+        i += rep;
+        prev = val;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return L.lens[256] != 0;  // a block without an end-of-block code is not valid
+}
+
 // status bits of one gzip file
 constexpr uint32_t kGzBadHeader = 1u, kGzBadData = 2u, kGzTruncated = 4u, kGzOverflow = 8u, kGzBadSize = 16u;
 
@@ -174,28 +276,55 @@ struct GzJob {
     uint64_t out_off, out_cap;   // where the text goes, and how much room there is
 };
 
-__global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restrict__ gz, uint8_t* __restrict__ out,
-                                                         const GzJob* __restrict__ jobs, uint32_t njobs,
-                                                         unsigned long long* __restrict__ out_len,
-                                                         uint32_t* __restrict__ status) {
-    __shared__ GzLds L;
-    const uint32_t job = blockIdx.x;
-    if (job >= njobs) return;
-    const int lane = threadIdx.x & 63;
-    const uint8_t* in = gz + jobs[job].in_off;
-    const uint64_t nbytes = jobs[job].in_len;
-    uint8_t* dst = out + jobs[job].out_off;
-    const uint64_t cap = jobs[job].out_cap;
-    const uint64_t nbits = nbytes * 8;
+// A CHUNK of a large gzip file (the chunked path, below): one wavefront decodes the DEFLATE blocks
+// from the block start `start_bit` (found by vk_gzfind_kernel; chunk 0: the gzip header at bit 0)
+// up to the block start of a later chunk.
+struct GzChunk {
+    uint64_t in_off, in_len;     // the whole FILE's compressed bytes
+    uint64_t out_off, out_cap;   // this chunk's u16 elements in the symbolic buffer (offset and room, in elements)
+    uint32_t file_chunk0;        // index of the file's chunk 0 in the chunk arrays
+    uint32_t nchunks;            // chunks of the file
+};
+constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
+constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
 
-    uint64_t pos = 0;      // bit position in the input (wave-uniform, like everything that steers the loops)
-    uint64_t opos = 0;     // bytes of text written
+// The decoder of one wavefront.  SYM = false: a whole file, text bytes straight to `out8`.
+// SYM = true: one chunk of a file whose preceding 32 KiB of text are not known yet: u16 elements to
+// `out16`, a value below 256 is a text byte, 0x8000 | w stands for byte w of that unknown window
+// (w = 32768 + position relative to the chunk's first byte); vk_gzwin_kernel / vk_gzfinal_kernel
+// replace them once the windows are known.
+template <bool SYM>
+__device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
+                        uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
+                        uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
+                        uint64_t& out_endbit) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t nbits = nbytes * 8;
+    uint64_t pos = start_bit;   // bit position in the input (wave-uniform, like everything that steers the loops)
+    uint64_t opos = 0;          // text bytes (elements) written
     uint32_t st = 0;
     uint32_t nring = 0;
+    uint32_t next = kGzEnd;
+    uint32_t jn = my_chunk + 1;  // SYM: the next chunk whose block start has not been passed yet
+    // how far back a distance may reach at output offset `off`: to the start of the gzip member, which in
+    // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
+    bool window_open = SYM && !at_header;
+    uint64_t member_text0 = 0;
+
+    auto load_elem = [&](long long p) -> uint32_t {  // element at output position p (p < 0: the unknown window)
+        if (SYM) {
+            if (p < 0) return 0x8000u | static_cast<uint32_t>(p + 32768);
+            return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto store_elem = [&](uint64_t p, uint32_t v) {
+        if (SYM) out16[p] = static_cast<uint16_t>(v);
+        else out8[p] = static_cast<uint8_t>(v);
+    };
 
     // The ring's tokens -> text.  Output offsets by prefix sum; then rounds: the longest run of tokens
     // whose sources are already written goes out in parallel, the stores are awaited, and so on.
-    uint64_t member_text0 = 0;  // text offset where the current member starts (distances cannot reach below it)
     auto resolve = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ring was written by other lanes of this wave
         __builtin_amdgcn_wave_barrier();
@@ -217,13 +346,15 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
             const uint32_t total = __shfl(incl, 63);
             const uint64_t off = base + (incl - len);  // where this lane's token starts
             if (base + total > cap) { st |= kGzOverflow; break; }
-            // a distance beyond the text written so far (in this gzip member) is an error
-            const bool bad = live && is_match && (dist == 0u || dist > off - member_text0);
+            // a distance beyond the start of the gzip member is an error
+            const uint64_t reach = window_open ? off + 32768u : off - member_text0;
+            const bool bad = live && is_match && (dist == 0u || dist > reach || dist > 32768u);
             if (__any(bad)) { st |= kGzBadData; break; }
             // source ends (exclusive) and rounds
-            const uint64_t src_end = is_match ? off - dist + (len < dist ? len : dist) : 0;
-            uint64_t frontier = base;          // everything below is written and visible
-            uint32_t done = 0;                 // tokens [0, done) of this group are out
+            const long long src0 = static_cast<long long>(off) - static_cast<long long>(dist);
+            const long long src_end = is_match ? src0 + static_cast<long long>(len < dist ? len : dist) : 0;
+            long long frontier = static_cast<long long>(base);  // everything below is written and visible
+            uint32_t done = 0;                                  // tokens [0, done) of this group are out
             const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
             while (done < ngroup) {
                 const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
@@ -236,13 +367,9 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
                 const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
                 // short tokens: one lane each
                 if (mine && !is_match) {
-                    dst[off] = static_cast<uint8_t>(tok);
+                    store_elem(off, tok & 0xFFu);
                 } else if (mine && len < kLongMatch) {
-                    const uint8_t* src = dst + (off - dist);
-                    for (uint32_t i = 0; i < len; ++i) {
-                        const uint8_t b = __hip_atomic_load(src + (i < dist ? i : i % dist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dst[off + i] = b;
-                    }
+                    for (uint32_t i = 0; i < len; ++i) store_elem(off + i, load_elem(src0 + (i < dist ? i : i % dist)));
                 }
                 // long matches: the whole wave, one after the other (sources below the frontier: independent)
                 unsigned long long lb = __ballot(mine && is_match && len >= kLongMatch);
@@ -252,15 +379,13 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
                     const uint32_t mlen = __shfl(len, l), mdist = __shfl(dist, l);
                     const uint32_t lo = __shfl(static_cast<uint32_t>(off), l), hi = __shfl(static_cast<uint32_t>(off >> 32), l);
                     const uint64_t moff = (static_cast<uint64_t>(hi) << 32) | lo;
-                    const uint8_t* src = dst + (moff - mdist);
-                    for (uint32_t i = lane; i < mlen; i += 64) {
-                        const uint8_t b = __hip_atomic_load(src + (i < mdist ? i : i % mdist), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        dst[moff + i] = b;
-                    }
+                    const long long msrc = static_cast<long long>(moff) - static_cast<long long>(mdist);
+                    for (uint32_t i = lane; i < mlen; i += 64) store_elem(moff + i, load_elem(msrc + (i < mdist ? i : i % mdist)));
                 }
                 __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
                 done = upto;
-                frontier = upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total;  // start of the first token still to do
+                // start of the first token still to do
+                frontier = static_cast<long long>(upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total);
             }
             base += total;
         }
@@ -270,34 +395,40 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 
     // ---- gzip members ---------------------------------------------------------------------------
     bool any_member = false;
-    while (st == 0) {
-        // trailing zero padding after the last member is tolerated (as Python's gzip module does)
-        if (any_member) {
-            while ((pos >> 3) < nbytes && in[pos >> 3] == 0) pos += 8;
-            if ((pos >> 3) >= nbytes) break;
+    bool in_member = !at_header;  // a chunk that starts at a block start is inside a member already
+    bool stop = false;
+    while (st == 0 && !stop) {
+        if (!in_member) {
+            // trailing zero padding after the last member is tolerated (as Python's gzip module does)
+            if (any_member) {
+                while ((pos >> 3) < nbytes && in[pos >> 3] == 0) pos += 8;
+                if ((pos >> 3) >= nbytes) break;
+            }
+            if ((pos >> 3) + 18 > nbytes) { st |= any_member ? kGzTruncated : kGzBadHeader; break; }
+            const uint8_t* h = in + (pos >> 3);
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) { st |= kGzBadHeader; break; }
+            const uint32_t flg = h[3];
+            uint64_t p = (pos >> 3) + 10;
+            if (flg & 4) {  // FEXTRA
+                if (p + 2 > nbytes) { st |= kGzTruncated; break; }
+                p += 2 + (static_cast<uint32_t>(in[p]) | (static_cast<uint32_t>(in[p + 1]) << 8));
+            }
+            if (flg & 8) {  // FNAME
+                while (p < nbytes && in[p] != 0) ++p;
+                ++p;
+            }
+            if (flg & 16) {  // FCOMMENT
+                while (p < nbytes && in[p] != 0) ++p;
+                ++p;
+            }
+            if (flg & 2) p += 2;  // FHCRC
+            if (p + 8 > nbytes) { st |= kGzTruncated; break; }
+            pos = p * 8;
+            member_text0 = opos;
+            window_open = false;  // a member starts with an empty window
         }
-        if ((pos >> 3) + 18 > nbytes) { st |= any_member ? kGzTruncated : kGzBadHeader; break; }
-        const uint8_t* h = in + (pos >> 3);
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) { st |= kGzBadHeader; break; }
-        const uint32_t flg = h[3];
-        uint64_t p = (pos >> 3) + 10;
-        if (flg & 4) {  // FEXTRA
-            if (p + 2 > nbytes) { st |= kGzTruncated; break; }
-            p += 2 + (static_cast<uint32_t>(in[p]) | (static_cast<uint32_t>(in[p + 1]) << 8));
-        }
-        if (flg & 8) {  // FNAME
-            while (p < nbytes && in[p] != 0) ++p;
-            ++p;
-        }
-        if (flg & 16) {  // FCOMMENT
-            while (p < nbytes && in[p] != 0) ++p;
-            ++p;
-        }
-        if (flg & 2) p += 2;  // FHCRC
-        if (p + 8 > nbytes) { st |= kGzTruncated; break; }
-        pos = p * 8;
         any_member = true;
-        member_text0 = opos;
+        in_member = false;  // (the block loop below runs the member to its end, or stops at a chunk boundary)
 
         // ---- DEFLATE blocks ---------------------------------------------------------------------
         bool last = false;
@@ -307,6 +438,7 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
             last = (w & 1u) != 0u;
             const uint32_t type = static_cast<uint32_t>(w >> 1) & 3u;
             pos += 3;
+            bool block_done = false;
             if (type == 0) {  // stored
                 pos = (pos + 7) & ~7ull;
                 const uint64_t b = pos >> 3;
@@ -318,201 +450,118 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
                 resolve();
                 if (st) break;
                 if (opos + len > cap) { st |= kGzOverflow; break; }
-                for (uint32_t i = lane; i < len; i += 64) dst[opos + i] = in[b + 4 + i];
+                for (uint32_t i = lane; i < len; i += 64) store_elem(opos + i, in[b + 4 + i]);
                 __builtin_amdgcn_s_waitcnt(0x0070);
                 opos += len;
                 pos = (b + 4 + len) * 8;
-                continue;
-            }
-            if (type == 3) { st |= kGzBadData; break; }
-            uint32_t nlit, ndist;
-            if (type == 1) {  // fixed codes
-                for (uint32_t i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
-                if (lane < 32) L.lens[288 + lane] = 5;
-                nlit = 288;
-                ndist = 32;  // 32 five-bit codes make the set complete; 30 and 31 never occur in valid data
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else {  // dynamic codes
-                w = gz_peek(in, nbytes, pos);
-                nlit = (static_cast<uint32_t>(w) & 31u) + 257;
-                ndist = (static_cast<uint32_t>(w >> 5) & 31u) + 1;
-                const uint32_t ncode = (static_cast<uint32_t>(w >> 10) & 15u) + 4;
-                pos += 14;
-                if (nlit > 286 || ndist > 30) { st |= kGzBadData; break; }
-                // code-length code: 19 lengths of 3 bits in a fixed order
-                uint32_t pl[19];
-#pragma unroll
-                for (int i = 0; i < 19; ++i) pl[i] = 0;
-                w = gz_peek(in, nbytes, pos);
-                for (uint32_t i = 0; i < ncode; ++i) {
-                    const uint32_t v = static_cast<uint32_t>(w >> (3 * i)) & 7u;
-#pragma unroll
-                    for (int k = 0; k < 19; ++k) pl[k] = (kPreOrder[i] == k) ? v : pl[k];
-                }
-                pos += 3 * ncode;
-                // 7-bit lookup table for it (small: every lane computes all of it, lane 0 stores)
-                {
-                    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, first[8];
-#pragma unroll
-                    for (int k = 0; k < 19; ++k) {
-#pragma unroll
-                        for (int l = 1; l < 8; ++l) cnt[l] += pl[k] == static_cast<uint32_t>(l) ? 1u : 0u;
-                    }
-                    int left = 1;
-                    uint32_t code = 0;
-                    first[0] = 0;
-                    bool ok = true;
-#pragma unroll
-                    for (int l = 1; l < 8; ++l) {
-                        left = left * 2 - static_cast<int>(cnt[l]);
-                        if (left < 0) ok = false;
-                        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
-                        first[l] = code;
-                    }
-                    if (!ok || left > 0) { st |= kGzBadData; break; }
-                    for (uint32_t i = lane; i < 128; i += 64) L.pre[i] = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        uint32_t next[8];
-#pragma unroll
-                        for (int l = 0; l < 8; ++l) next[l] = first[l];
-                        for (uint32_t s = 0; s < 19; ++s) {
-                            uint32_t l = 0;
-#pragma unroll
-                            for (int k = 0; k < 19; ++k) l = s == static_cast<uint32_t>(k) ? pl[k] : l;
-                            if (l == 0) continue;
-                            uint32_t c = 0;
-#pragma unroll
-                            for (int k = 1; k < 8; ++k) {
-                                if (l == static_cast<uint32_t>(k)) {
-                                    c = next[k];
-                                    next[k] = c + 1;
-                                }
-                            }
-                            for (uint32_t idx = gz_rev(c, l); idx < 128; idx += 1u << l) L.pre[idx] = static_cast<uint8_t>(s | (l << 5));
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                // the nlit + ndist code lengths, run-length coded with the code-length code
-                uint32_t i = 0, prev = 0;
-                bool ok = true;
-                while (i < nlit + ndist) {
-                    if (pos > nbits) { ok = false; break; }
-                    w = gz_peek(in, nbytes, pos);
-                    const uint32_t e = L.pre[static_cast<uint32_t>(w) & 127u];
-                    const uint32_t l = e >> 5, s = e & 31u;
-                    if (l == 0) { ok = false; break; }
-                    pos += l;
-                    w >>= l;
-                    uint32_t rep = 1, val = s;
-                    if (s == 16) {
-                        if (i == 0) { ok = false; break; }
-                        rep = 3 + (static_cast<uint32_t>(w) & 3u);
-                        val = prev;
-                        pos += 2;
-                    } else if (s == 17) {
-                        rep = 3 + (static_cast<uint32_t>(w) & 7u);
-                        val = 0;
-                        pos += 3;
-                    } else if (s == 18) {
-                        rep = 11 + (static_cast<uint32_t>(w) & 127u);
-                        val = 0;
-                        pos += 7;
-                    }
-                    if (i + rep > nlit + ndist) { ok = false; break; }
-                    if (lane == 0)
-                        for (uint32_t r = 0; r < rep; ++r) L.lens[(i + r < nlit ? i + r : 288 + (i + r - nlit))] = static_cast<uint8_t>(val);
-                    i += rep;
-                    prev = val;
-                }
-                if (!ok) { st |= kGzBadData; break; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (L.lens[256] == 0) { st |= kGzBadData; break; }  // no end-of-block code
-            }
-            if (!gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) ||
-                !gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane)) {
+                block_done = true;
+            } else if (type == 3) {
                 st |= kGzBadData;
                 break;
             }
+            if (!block_done) {
+                uint32_t nlit, ndist;
+                if (type == 1) {  // fixed codes
+                    for (uint32_t i = lane; i < 288; i += 64) L.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                    if (lane < 32) L.lens[288 + lane] = 5;
+                    nlit = 288;
+                    ndist = 32;  // 32 five-bit codes make the set complete; 30 and 31 never occur in valid data
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else if (!gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane)) {
+                    st |= kGzBadData;
+                    break;
+                }
+                if (!gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) ||
+                    !gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane)) {
+                    st |= kGzBadData;
+                    break;
+                }
 
-            // ---- tokens ---------------------------------------------------------------------
-            bool eob = false;
-            while (!eob && st == 0) {
-                if (pos >= nbits) { st |= kGzTruncated; break; }
-                if (nring + 64 > kRing) {
-                    resolve();
-                    if (st) break;
-                }
-                // every lane: the token that would start at pos + lane
-                const uint64_t ww = gz_peek(in, nbytes, pos + lane);
-                uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
-                uint32_t used = e & 15u;
-                if (used == 15u) {  // a long code (rare)
-                    uint32_t l;
-                    const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
-                    used = l;
-                    if (s < 256) e = (s << 16) | (kKindLit << 8);
-                    else if (s == 256) e = kKindEob << 8;
-                    else if (s < 286) e = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
-                    else e = kKindBad << 8;
-                }
-                uint32_t kind = (e >> 8) & 3u;
-                uint32_t tok = e >> 16;  // literal byte
-                if (kind == kKindLen) {
-                    const uint32_t xb = (e >> 4) & 15u;
-                    const uint32_t len = (e >> 16) + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
-                    used += xb;
-                    const uint64_t w2 = ww >> used;
-                    uint32_t d = L.dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
-                    uint32_t dl = d & 15u;
-                    if (dl == 15u) {
+                // ---- tokens -----------------------------------------------------------------
+                bool eob = false;
+                while (!eob && st == 0) {
+                    if (pos >= nbits) { st |= kGzTruncated; break; }
+                    if (nring + 64 > kRing) {
+                        resolve();
+                        if (st) break;
+                    }
+                    // every lane: the token that would start at pos + lane
+                    const uint64_t ww = gz_peek(in, nbytes, pos + lane);
+                    uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
+                    uint32_t used = e & 15u;
+                    if (used == 15u) {  // a long code (rare)
                         uint32_t l;
-                        const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
-                        dl = l;
-                        d = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
-                                   : (kKindBad << 8);
+                        const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
+                        used = l;
+                        if (s < 256) e = (s << 16) | (kKindLit << 8);
+                        else if (s == 256) e = kKindEob << 8;
+                        else if (s < 286) e = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
+                        else e = kKindBad << 8;
                     }
-                    if (((d >> 8) & 3u) != kKindLen || dl == 0u) {
-                        kind = kKindBad;
-                    } else {
-                        const uint32_t dxb = (d >> 4) & 15u;
-                        const uint32_t dist = (d >> 16) + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
-                        used += dl + dxb;
-                        tok = 0x80000000u | (dist << 9) | len;
+                    uint32_t kind = (e >> 8) & 3u;
+                    uint32_t tok = e >> 16;  // literal byte
+                    if (kind == kKindLen) {
+                        const uint32_t xb = (e >> 4) & 15u;
+                        const uint32_t len = (e >> 16) + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
+                        used += xb;
+                        const uint64_t w2 = ww >> used;
+                        uint32_t d = L.dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
+                        uint32_t dl = d & 15u;
+                        if (dl == 15u) {
+                            uint32_t l;
+                            const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
+                            dl = l;
+                            d = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
+                                       : (kKindBad << 8);
+                        }
+                        if (((d >> 8) & 3u) != kKindLen || dl == 0u) {
+                            kind = kKindBad;
+                        } else {
+                            const uint32_t dxb = (d >> 4) & 15u;
+                            const uint32_t dist = (d >> 16) + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
+                            used += dl + dxb;
+                            tok = 0x80000000u | (dist << 9) | len;
+                        }
                     }
-                }
-                if (used == 0u) kind = kKindBad;
-                // the true chain through the 64 answers
-                unsigned long long chain = 0;
-                uint32_t at = 0, ntok = 0;
-                bool bad = false;
-                while (at < 64) {
-                    const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
-                    if (k == kKindBad) { bad = true; break; }
-                    const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
-                    if (k == kKindEob) {
-                        eob = true;
+                    if (used == 0u) kind = kKindBad;
+                    // the true chain through the 64 answers
+                    unsigned long long chain = 0;
+                    uint32_t at = 0, ntok = 0;
+                    bool bad = false;
+                    while (at < 64) {
+                        const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
+                        if (k == kKindBad) { bad = true; break; }
+                        const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
+                        if (k == kKindEob) {
+                            eob = true;
+                            at += u;
+                            break;
+                        }
+                        chain |= 1ull << at;
+                        ++ntok;
                         at += u;
-                        break;
                     }
-                    chain |= 1ull << at;
-                    ++ntok;
-                    at += u;
+                    if (bad) { st |= kGzBadData; break; }
+                    if ((chain >> lane) & 1ull)
+                        L.ring[nring + __popcll(chain & ((1ull << lane) - 1ull))] = tok;
+                    nring += ntok;
+                    pos += at;
+                    if (pos > nbits) st |= kGzTruncated;  // the chain ran off the end of the file
                 }
-                if (bad) { st |= kGzBadData; break; }
-                if ((chain >> lane) & 1ull)
-                    L.ring[nring + __popcll(chain & ((1ull << lane) - 1ull))] = tok;
-                nring += ntok;
-                pos += at;
-                if (pos > nbits) st |= kGzTruncated;  // the chain ran off the end of the file
+                if (st) break;
+            }
+            // a block has ended at `pos`: in a chunk, stop where a later chunk begins
+            if (SYM && !last) {
+                while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;  // starts inside what was decoded: not block starts after all
+                if (jn < nchunks && starts[jn] == pos) {
+                    next = jn;
+                    stop = true;
+                    break;
+                }
             }
         }
-        if (st) break;
+        if (st || stop) break;
         resolve();
         if (st) break;
         // trailer: CRC32 (not verified here) and ISIZE
@@ -521,11 +570,32 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
         if (b + 8 > nbytes) { st |= kGzTruncated; break; }
         const uint32_t isize = in[b + 4] | (static_cast<uint32_t>(in[b + 5]) << 8) | (static_cast<uint32_t>(in[b + 6]) << 16) |
                                (static_cast<uint32_t>(in[b + 7]) << 24);
-        if (isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }
+        if (!window_open && isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }  // (a member that began in an earlier chunk is checked by the host: sum of the chunks)
         pos = (b + 8) * 8;
+        if (SYM) {  // the starts found inside what this chunk decoded (none, or false ones) are behind us
+            while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;
+        }
     }
-    if (lane == 0) {
-        out_len[job] = opos;
+    if (st == 0 && stop) resolve();
+    out_len = opos;
+    out_status = st;
+    out_next = next;
+    out_endbit = pos;
+}
+
+__global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restrict__ gz, uint8_t* __restrict__ out,
+                                                         const GzJob* __restrict__ jobs, uint32_t njobs,
+                                                         unsigned long long* __restrict__ out_len,
+                                                         uint32_t* __restrict__ status) {
+    __shared__ GzLds L;
+    const uint32_t job = blockIdx.x;
+    if (job >= njobs) return;
+    uint64_t n = 0, endbit = 0;
+    uint32_t st = 0, next = 0;
+    gz_wave<false>(L, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
+                   nullptr, 0, 0, n, st, next, endbit);
+    if ((threadIdx.x & 63) == 0) {
+        out_len[job] = n;
         status[job] = st;
     }
 }

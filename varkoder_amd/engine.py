@@ -108,73 +108,129 @@ class ImageEngine:
         return dev, offs, lens
 
     def stage_files(self, paths, pool=None, slot=0):
-        """Host half of upload_files: read the files into pinned staging buffer `slot` (kept and grown
-        across calls).  Plain FASTQ files are read straight into it (parallel readinto, no
-        intermediate copy); gzip files are inflated first.  May run on a thread of its own (a
-        pipeline stages the next batch while this one is copied and processed): the only GPU-runtime
-        call is the pinned allocation, made with this engine's device current.  A file that cannot
-        be read or inflated is staged with length 0 -- the caller sees an empty histogram for it and
-        skips it as the reference skips a file dsk fails on (commands/image.py:1070-1075) -- and
-        never takes the rest of the batch with it."""
-        import gzip
+        """Host half of upload_files: read the files, AS THEY ARE ON DISK, into pinned staging buffer
+        `slot` (kept and grown across calls) with parallel readinto, no intermediate copy.  Plain FASTQ
+        files land at their final 16-byte aligned text offsets; gzip files (what step C of the
+        reference writes, commands/image.py:696-708) stay compressed -- they cross PCIe that way and
+        are inflated on the GPU by upload_staged -- and only get their text slot reserved (its size is
+        the ISIZE word that ends a gzip file).  May run on a thread of its own (a pipeline stages the
+        next batch while this one is copied and processed): the only GPU-runtime call is the pinned
+        allocation, made with this engine's device current.  A file that cannot be read is staged with
+        length 0 -- the caller sees an empty histogram for it and skips it as the reference skips a
+        file dsk fails on (commands/image.py:1070-1075) -- and never takes the batch with it."""
         import os
-        import zlib
         torch = _torch()
         torch.cuda.set_device(self.device)  # thread-local: a fresh thread would otherwise allocate on device 0
 
         def probe(p):
+            """(is_gzip, bytes on disk, text bytes expected)"""
             try:
+                size = os.path.getsize(p)
                 with open(p, "rb") as f:
                     gz = f.read(2) == b"\x1f\x8b"
-                if gz:
-                    with gzip.open(p, "rb") as f:
-                        data = f.read()
-                    return len(data), data
-                return os.path.getsize(p), None
-            except (OSError, EOFError, zlib.error) as e:   # (gzip.BadGzipFile is an OSError)
+                    if not gz:
+                        return False, size, size
+                    if size < 18:
+                        return True, 0, 0
+                    f.seek(size - 4)
+                    return True, size, int.from_bytes(f.read(4), "little")
+            except OSError as e:
                 print("cannot read", str(p) + ":", repr(e), file=sys.stderr)
-                return 0, None
+                return False, 0, 0
         mapper = pool.map if pool is not None else map
         info = list(mapper(probe, paths))
-        lens = np.array([n for n, _ in info], dtype=np.uint64)
-        offs = np.zeros(len(paths), dtype=np.uint64)
+        n = len(paths)
+        is_gz = np.array([g for g, _, _ in info], dtype=bool)
+        disk = np.array([d for _, d, _ in info], dtype=np.uint64)
+        lens = np.array([0 if g else t for g, _, t in info], dtype=np.uint64)      # gzip: known after the inflate
+        caps = np.array([t for _, _, t in info], dtype=np.uint64)                  # text slot sizes
+        # text layout: plain files first, then the slots of the gzip files
+        offs = np.zeros(n, dtype=np.uint64)
         pos = 0
-        for i, n in enumerate(lens):
+        for i in np.flatnonzero(~is_gz):
             offs[i] = pos
-            pos += (int(n) + 15) // 16 * 16
-        total = pos + 16
+            pos += (int(caps[i]) + 15) // 16 * 16
+        plain_total = pos
+        for i in np.flatnonzero(is_gz):
+            offs[i] = pos
+            pos += (int(caps[i]) + 15) // 16 * 16
+        text_total = pos + 16
+        # staging layout: the plain region as it will sit on the device, then the compressed files
+        src = np.zeros(n, dtype=np.uint64)
+        src[~is_gz] = offs[~is_gz]
+        pos = plain_total
+        for i in np.flatnonzero(is_gz):
+            src[i] = pos
+            pos += (int(disk[i]) + 15) // 16 * 16
+        stage_total = pos + 16
         slots = self.__dict__.setdefault("_pinned_slots", {})
         pinned = slots.get(slot)
-        if pinned is None or pinned.numel() < total:
-            pinned = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        if pinned is None or pinned.numel() < stage_total:
+            pinned = torch.empty(max(stage_total, 1 << 20), dtype=torch.uint8, pin_memory=True)
             slots[slot] = pinned
         host = pinned.numpy()
 
         def fill(i):
-            o, n = int(offs[i]), int(lens[i])
-            if info[i][1] is not None:
-                host[o:o + n] = np.frombuffer(info[i][1], dtype=np.uint8)
-            elif n:
+            o, nb = int(src[i]), int(disk[i])
+            got = 0
+            if nb:
                 try:
                     with open(paths[i], "rb") as f:
-                        got = f.readinto(memoryview(host[o:o + n]))
+                        got = f.readinto(memoryview(host[o:o + nb]))
                 except OSError as e:
                     print("cannot read", str(paths[i]) + ":", repr(e), file=sys.stderr)
                     got = -1
-                if got != n:      # unreadable or changed under us: an empty sample, not a dead batch
+                if got != nb:      # unreadable or changed under us: an empty sample, not a dead batch
+                    disk[i] = 0
                     lens[i] = 0
-            host[o + n:(o + n + 15) // 16 * 16] = 0
-        list(mapper(fill, range(len(paths))))
-        host[pos:total] = 0
-        return pinned, total, offs, lens
+                    caps[i] = 0
+            host[o + nb:(o + nb + 15) // 16 * 16] = 0
+        list(mapper(fill, range(n)))
+        return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
+                "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
+                "paths": [str(p) for p in paths]}
 
     def upload_staged(self, staged):
-        """Device half: one H2D DMA of a staged batch; returns (tensor, offsets, lengths).  The
-        staging buffer may be refilled once this returns."""
+        """Device half: one H2D DMA of the plain text, one of the compressed files, and the gzip files
+        inflated in HBM into their text slots (vk_inflate_device).  Returns (tensor, offsets, lengths);
+        the staging buffer may be refilled once this returns.  A gzip file the GPU rejects (bad header
+        or data, truncated, size word wrong) gets length 0 and a line on stderr."""
         torch = _torch()
-        pinned, total, offs, lens = staged
-        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
-        dev.copy_(pinned[:total], non_blocking=True)
+        pinned, plain_total, stage_total = staged["pinned"], staged["plain_total"], staged["stage_total"]
+        offs, lens, is_gz = staged["offs"], staged["lens"].copy(), staged["is_gz"]
+        dev = torch.empty(staged["text_total"], dtype=torch.uint8, device=self.device)
+        if plain_total:
+            dev[:plain_total].copy_(pinned[:plain_total], non_blocking=True)
+        gi = np.flatnonzero(is_gz & (staged["disk"] > 0))
+        if gi.size:
+            gzdev = torch.empty(stage_total - plain_total, dtype=torch.uint8, device=self.device)
+            gzdev.copy_(pinned[plain_total:stage_total], non_blocking=True)
+            got, st = self.inflate(gzdev, staged["src"][gi] - np.uint64(plain_total), staged["disk"][gi], dev,
+                                   offs[gi], staged["caps"][gi])
+            over = [j for j in range(gi.size) if st[j] == _capi.VK_GZ_OVERFLOW]
+            if over:
+                # more text than the last member's size word promised (a multi-member file): inflate those
+                # again into a side buffer with room for 32x their compressed size and append it
+                oi = gi[over]
+                c2 = staged["disk"][oi] * np.uint64(32) + np.uint64(1 << 16)
+                o2 = np.zeros(oi.size, dtype=np.uint64)
+                p = 0
+                for j in range(oi.size):
+                    o2[j] = p
+                    p += (int(c2[j]) + 15) // 16 * 16
+                side = torch.empty(p + 16, dtype=torch.uint8, device=self.device)
+                g2, s2 = self.inflate(gzdev, staged["src"][oi] - np.uint64(plain_total), staged["disk"][oi], side, o2, c2)
+                base = dev.numel()
+                dev = torch.cat([dev, side])
+                for j, jj in enumerate(over):
+                    got[jj], st[jj] = g2[j], s2[j]
+                    offs = offs.copy() if offs is staged["offs"] else offs
+                    offs[oi[j]] = base + int(o2[j])
+            for j, i in enumerate(gi):
+                if st[j]:
+                    print(f"gzip inflate failed (status {int(st[j])}):", staged["paths"][i], file=sys.stderr)
+                else:
+                    lens[i] = got[j]
         torch.cuda.current_stream(self.device).synchronize()
         return dev, offs, lens
 

@@ -165,13 +165,18 @@ def count_kmers(infile, outfolder, threads=1, k=7, overwrite=False, verbose=Fals
         eprint("File exists. Skipping kmer counting for file:", str(infile))
         return OrderedDict()
 
-    data = read_fastq_bytes(infile)
-    hist, status = _engine(k, "count").count_host(data)
+    # the file crosses PCIe as it is on disk; a .gz is inflated on the GPU (dsk reads .gz natively)
+    eng = _engine(k, "count")
+    dev, offs, lens = eng.upload_files([infile])
+    if Path(infile).stat().st_size and not int(lens[0]):
+        raise RuntimeError(f"k-mer counting failed for {infile}: not a readable FASTQ / gzip file")
+    h, st = eng.count(dev, offs, lens)
+    hist, status = h.cpu().numpy().view(np.uint32)[0], int(st.cpu()[0])
     if status:
         raise RuntimeError(f"k-mer counting failed for {infile}: inconsistent FASTQ framing "
                            f"(status bits {status})")
     if verbose:
-        eprint(f"vk_count_host k={k} bytes={len(data)} windows={int(hist.sum(dtype=np.uint64))}")
+        eprint(f"vk_count_device k={k} bytes={int(lens[0])} windows={int(hist.sum(dtype=np.uint64))}")
     write_counts(outpath, k, hist)
     return OrderedDict([(f"{k}mer_counting_time", _seconds_since(t0))])
 

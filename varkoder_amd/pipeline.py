@@ -53,10 +53,10 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         todo.append(f)
 
     import os
-    # batches by on-disk size (gzip files count 4x: they are inflated on the host first)
+    # batches by text size in HBM (gzip files count 6x their size on disk: they are inflated on the GPU)
     batches, batch, nbytes = [], [], 0
     for f in todo:
-        sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
+        sz = os.path.getsize(f) * (6 if f.suffix == ".gz" else 1)
         if batch and nbytes + sz > batch_bytes:
             batches.append((batch, nbytes))
             batch, nbytes = [], 0
@@ -137,7 +137,7 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
         batch, nbytes = [], 0
         t0 = time.perf_counter()
         for f in mine[i:]:
-            sz = os.path.getsize(f) * (4 if f.suffix == ".gz" else 1)
+            sz = os.path.getsize(f) * (6 if f.suffix == ".gz" else 1)
             if batch and nbytes + sz > batch_bytes:
                 break
             batch.append(f)

@@ -127,3 +127,33 @@ def test_inflate_many_files_and_a_big_one(engines):
     assert got[0] == big
     for i in range(40):
         assert got[1 + i] == synth.sample_fastq(100 + i, 300 + 17 * i, 150, dist=i & 1).tobytes(), i
+
+
+def test_inflate_large_files_take_many_wavefronts_and_agree(engines):
+    """Files of 512 KiB and more go through the chunked path (block starts found in every 256 KiB of the
+    compressed stream, chunks decoded with a symbolic window, windows propagated, markers resolved):
+    same bytes as zlib for every level, for streams with stored blocks and long runs in them, and for a
+    large multi-member file."""
+    eng = engines(7)
+    rng = np.random.default_rng(11)
+    fq = [synth.sample_fastq(20 + i, 60000, 150, dist=i & 1).tobytes() for i in range(3)]      # 19 MB each
+    noise = rng.integers(0, 256, size=3_000_000, dtype=np.uint8).tobytes()
+    mixed = fq[0][:4_000_000] + noise + b"A" * 2_000_000 + fq[1][:5_000_000] + noise[:700_000] + b"ACGT" * 500_000
+    texts = [fq[0], fq[1], fq[2], mixed, fq[0] + fq[1]]
+    files = [gz(fq[0], 1), gz(fq[1], 6), gz(fq[2], 9), gz(mixed, 6), gz(fq[0], 6) + gz(fq[1], 4)]
+    assert all(len(f) >= 2 * (1 << 18) for f in files)
+    got, status, _, _ = run(eng, files, caps=[len(t) for t in texts])
+    assert status.tolist() == [0] * len(files)
+    for i, (g, t) in enumerate(zip(got, texts)):
+        assert len(g) == len(t), i
+        assert g == t, i
+    # a multi-member file whose caller knows only the last member's size: told to come back with more room
+    got, status, _, _ = run(eng, [files[4]])
+    assert status[0] == _capi.VK_GZ_OVERFLOW
+    # damage in the middle of a large file is reported, not decoded around
+    bad = bytearray(files[1])
+    bad[len(bad) // 2] ^= 0xFF
+    bad[len(bad) // 2 + 1] ^= 0xFF
+    got, status, _, _ = run(eng, [bytes(bad)], caps=[len(texts[1])])
+    assert status[0] != 0 or got[0] != texts[1]
+    assert status[0] != 0

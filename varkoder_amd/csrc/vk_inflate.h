@@ -297,7 +297,7 @@ template <bool SYM>
 __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
                         uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
                         uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
-                        uint64_t& out_endbit) {
+                        uint64_t& out_endbit, uint32_t& out_isize_sum) {
     const int lane = threadIdx.x & 63;
     const uint64_t nbits = nbytes * 8;
     uint64_t pos = start_bit;   // bit position in the input (wave-uniform, like everything that steers the loops)
@@ -305,6 +305,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     uint32_t st = 0;
     uint32_t nring = 0;
     uint32_t next = kGzEnd;
+    uint32_t isize_sum = 0;      // sum (mod 2^32) of the ISIZE words of the member trailers passed: the host checks it against the text
     uint32_t jn = my_chunk + 1;  // SYM: the next chunk whose block start has not been passed yet
     // how far back a distance may reach at output offset `off`: to the start of the gzip member, which in
     // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
@@ -571,6 +572,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
         const uint32_t isize = in[b + 4] | (static_cast<uint32_t>(in[b + 5]) << 8) | (static_cast<uint32_t>(in[b + 6]) << 16) |
                                (static_cast<uint32_t>(in[b + 7]) << 24);
         if (!window_open && isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }  // (a member that began in an earlier chunk is checked by the host: sum of the chunks)
+        isize_sum += isize;
         pos = (b + 8) * 8;
         if (SYM) {  // the starts found inside what this chunk decoded (none, or false ones) are behind us
             while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;
@@ -581,6 +583,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     out_status = st;
     out_next = next;
     out_endbit = pos;
+    out_isize_sum = isize_sum;
 }
 
 __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restrict__ gz, uint8_t* __restrict__ out,
@@ -591,12 +594,155 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
     uint64_t n = 0, endbit = 0;
-    uint32_t st = 0, next = 0;
+    uint32_t st = 0, next = 0, isum = 0;
     gz_wave<false>(L, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
-                   nullptr, 0, 0, n, st, next, endbit);
+                   nullptr, 0, 0, n, st, next, endbit, isum);
     if ((threadIdx.x & 63) == 0) {
         out_len[job] = n;
         status[job] = st;
+    }
+}
+
+// ---- the chunked path: many wavefronts per file ---------------------------------------------------
+// A gzip file is ONE chain of tokens, but its DEFLATE blocks can be decoded independently once two
+// things are known: where a block starts, and the 32 KiB of text before it (matches reach back that
+// far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every 256 KiB chunk of
+// the compressed file: a cheap test of every bit offset by 64 lanes (block type, code counts, the
+// code-length code must be complete), then the full header parse and table build of the decoder for
+// the few that pass.  (2) vk_gzchunk_kernel decodes every chunk from its start to the start of a later
+// chunk, with the unknown window kept symbolic (gz_wave<true>).  A start that was not a real block
+// start is never reached exactly by the chunk before it, which simply decodes on to the next one; the
+// host follows the `next` links from chunk 0.  (3) vk_gzwin_kernel walks the chunks of a file in order
+// and turns each chunk's last 32 KiB into the next chunk's window, (4) vk_gzfinal_kernel replaces the
+// markers and writes the text.  Anything unexpected (no start found, a chunk that overflows its
+// room, sizes that do not add up) sends the file through vk_inflate_kernel instead.
+constexpr uint32_t kGzChunkBytes = 1u << 18;
+
+__global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
+                                                        uint32_t nchunks_total, uint64_t* __restrict__ starts) {
+    __shared__ GzLds L;
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks_total) return;
+    const GzChunk ch = chunks[c];
+    const int lane = threadIdx.x & 63;
+    const uint32_t j = c - ch.file_chunk0;
+    if (j == 0) {  // the file's first chunk starts at the gzip header
+        if (lane == 0) starts[c] = 0;
+        return;
+    }
+    const uint8_t* in = gz + ch.in_off;
+    const uint64_t nbytes = ch.in_len, nbits = nbytes * 8;
+    const uint64_t from = static_cast<uint64_t>(j) * kGzChunkBytes * 8;
+    uint64_t to = from + static_cast<uint64_t>(kGzChunkBytes) * 8;
+    if (to + 80 > nbits) to = nbits > 80 ? nbits - 80 : 0;  // (a header needs more bits than that anyway)
+    uint64_t found = kGzNone;
+    for (uint64_t p0 = from; p0 < to && found == kGzNone; p0 += 64) {
+        const uint64_t p = p0 + lane;
+        const uint64_t w = gz_peek(in, nbytes, p);
+        // not the last block, dynamic codes, at most 286 literal/length and 30 distance codes
+        bool cand = p < to && (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
+        if (cand) {  // the code-length code must be complete: sum of 2^-len = 1
+            const uint32_t ncode = (static_cast<uint32_t>(w >> 13) & 15u) + 4;
+            const uint64_t w2 = gz_peek(in, nbytes, p + 17);
+            uint32_t kraft = 0;
+            for (uint32_t i = 0; i < ncode; ++i) {
+                const uint32_t v = static_cast<uint32_t>(w2 >> (3 * i)) & 7u;
+                kraft += v ? (128u >> v) : 0u;
+            }
+            cand = kraft == 128u;
+        }
+        unsigned long long b = __ballot(cand);
+        while (b && found == kGzNone) {  // the full test, by the whole wave, in stream order
+            const int l = __builtin_ctzll(b);
+            b &= b - 1;
+            uint64_t pos = p0 + l + 3;
+            uint32_t nlit, ndist;
+            if (gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
+                gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
+                gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane))
+                found = p0 + l;
+        }
+    }
+    if (lane == 0) starts[c] = found;
+}
+
+__global__ __launch_bounds__(64) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
+                                                         const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
+                                                         const uint64_t* __restrict__ starts,
+                                                         unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
+                                                         uint32_t* __restrict__ next, uint32_t* __restrict__ isize_sum) {
+    __shared__ GzLds L;
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks_total) return;
+    const GzChunk ch = chunks[c];
+    const uint32_t j = c - ch.file_chunk0;
+    uint64_t n = 0, eb = 0;
+    uint32_t st = 0, nx = kGzEnd, isum = 0;
+    const uint64_t s0 = starts[c];
+    if (s0 == kGzNone) {
+        st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
+    } else {
+        gz_wave<true>(L, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
+                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        out_len[c] = n;
+        status[c] = st;
+        next[c] = nx == kGzEnd ? kGzEnd : ch.file_chunk0 + nx;
+        isize_sum[c] = isum;
+    }
+}
+
+// One workgroup per file: chunk after chunk of its chain, the 32 KiB window a chunk sees (win_in[k]) and the
+// one it leaves behind.  items: {chunk's element offset, its length}; first/count: the file's slice of them.
+struct GzItem {
+    uint64_t sym_off, len, text_off;
+};
+
+__global__ __launch_bounds__(1024) void vk_gzwin_kernel(const uint16_t* __restrict__ sym, const GzItem* __restrict__ items,
+                                                         const uint32_t* __restrict__ first, const uint32_t* __restrict__ count,
+                                                         uint8_t* __restrict__ win_in) {
+    __shared__ uint8_t win[2][32768];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < 32768; i += 1024) win[0][i] = 0;
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t k = first[f]; k < first[f] + count[f]; ++k) {
+        const uint8_t* old = win[cur];
+        uint8_t* nw = win[cur ^ 1];
+        uint8_t* dst = win_in + static_cast<uint64_t>(k) * 32768;
+        for (uint32_t i = tid; i < 32768 / 16; i += 1024)
+            reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(old)[i];
+        const uint64_t n = items[k].len;
+        const uint16_t* e = sym + items[k].sym_off;
+        const uint32_t keep = n >= 32768 ? 0u : 32768u - static_cast<uint32_t>(n);  // bytes of the old window that stay
+        for (uint32_t i = tid; i < 32768; i += 1024) {
+            uint32_t v;
+            if (i < keep) {
+                v = old[i + (32768 - keep)];
+            } else {
+                const uint32_t x = e[n - (32768 - i)];
+                v = x < 0x8000u ? x : old[x & 0x7FFFu];
+            }
+            nw[i] = static_cast<uint8_t>(v);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void vk_gzfinal_kernel(const uint16_t* __restrict__ sym, const GzItem* __restrict__ items,
+                                                          uint32_t nitems, const uint8_t* __restrict__ win_in,
+                                                          uint8_t* __restrict__ text) {
+    const uint32_t k = blockIdx.y;
+    if (k >= nitems) return;
+    const GzItem it = items[k];
+    const uint16_t* e = sym + it.sym_off;
+    const uint8_t* w = win_in + static_cast<uint64_t>(k) * 32768;
+    uint8_t* out = text + it.text_off;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < it.len; i += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint32_t x = e[i];
+        out[i] = static_cast<uint8_t>(x < 0x8000u ? x : w[x & 0x7FFFu]);
     }
 }
 

@@ -68,6 +68,13 @@ struct vk_ctx {
     uint64_t* d_sub = nullptr;    // subsampling launches: seeds | thresholds
     uint8_t* d_gzjobs = nullptr;  // vk_inflate_device: jobs | text lengths | status words
     size_t gzjobs_cap = 0;
+    uint8_t* d_gzmeta = nullptr;  // ... chunked path: chunk table and results, then the chain items
+    size_t gzmeta_cap = 0;
+    uint8_t* d_gzsym = nullptr;   // ... u16 elements of every chunk
+    size_t gzsym_cap = 0;
+    uint8_t* d_gzwin = nullptr;   // ... the 32 KiB window every chunk of a chain starts with
+    size_t gzwin_cap = 0;
+    bool gz_no_chunks = false;    // VKIMG_GZ_NO_CHUNKS=1: every file through the one-wavefront kernel (tests, A/B timing)
     size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
@@ -272,6 +279,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
     {
         const char* e = getenv("VKIMG_IMAGE_SORT_ONLY");
         ctx->image_sort_only = e && e[0] == '1';
+        const char* g = getenv("VKIMG_GZ_NO_CHUNKS");
+        ctx->gz_no_chunks = g && g[0] == '1';
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
     }
@@ -292,7 +301,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -482,22 +491,155 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
     if (nfiles == 0) return VK_OK;
     if (!d_gz || !d_out) return VK_EINVAL;
     VK_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t jobs_b = static_cast<size_t>(nfiles) * sizeof(GzJob), len_b = static_cast<size_t>(nfiles) * 8,
-                 st_b = static_cast<size_t>(nfiles) * 4;
-    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + st_b);
-    if (rc) return rc;
-    std::vector<GzJob> jobs(nfiles);
-    for (uint32_t i = 0; i < nfiles; ++i) jobs[i] = GzJob{gz_offsets[i], gz_lengths[i], out_offsets[i], out_caps[i]};
-    GzJob* d_jobs = reinterpret_cast<GzJob*>(ctx->d_gzjobs);
-    unsigned long long* d_len = reinterpret_cast<unsigned long long*>(ctx->d_gzjobs + jobs_b);
-    uint32_t* d_st = reinterpret_cast<uint32_t*>(ctx->d_gzjobs + jobs_b + len_b);
-    VK_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs_b, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(vk_inflate_kernel, dim3(nfiles), dim3(64), 0, ctx->stream, static_cast<const uint8_t*>(d_gz),
-                       static_cast<uint8_t*>(d_out), d_jobs, nfiles, d_len, d_st);
-    VK_HIP(ctx, hipGetLastError());
-    VK_HIP(ctx, hipMemcpyAsync(out_lengths, d_len, len_b, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP(ctx, hipMemcpyAsync(status, d_st, st_b, hipMemcpyDeviceToHost, ctx->stream));
-    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also keeps `jobs` alive until the copy has read it)
+    const uint8_t* gz = static_cast<const uint8_t*>(d_gz);
+    uint8_t* out = static_cast<uint8_t*>(d_out);
+    std::vector<uint32_t> direct;  // files that go through the one-wavefront-per-file kernel
+
+    // ---- large files: many wavefronts per file (vk_inflate.h, "the chunked path") ------------------
+    std::vector<uint32_t> big;
+    for (uint32_t i = 0; i < nfiles; ++i) {
+        out_lengths[i] = 0;
+        status[i] = 0;
+        if (!ctx->gz_no_chunks && gz_lengths[i] >= 2ull * kGzChunkBytes) big.push_back(i);
+        else direct.push_back(i);
+    }
+    if (!big.empty()) {
+        std::vector<GzChunk> chunks;
+        std::vector<uint32_t> chunk0(big.size());
+        uint64_t sym_total = 0;
+        for (size_t b = 0; b < big.size(); ++b) {
+            const uint32_t i = big[b];
+            const uint32_t nch = static_cast<uint32_t>((gz_lengths[i] + kGzChunkBytes - 1) / kGzChunkBytes);
+            // room per chunk (u16 elements): twice what the file's overall ratio predicts for 256 KiB, at least 8x
+            double ratio = static_cast<double>(out_caps[i]) / static_cast<double>(gz_lengths[i]);
+            if (ratio < 4.0) ratio = 4.0;
+            uint64_t cap = static_cast<uint64_t>(2.0 * ratio * kGzChunkBytes) + 65536;
+            if (cap > (1ull << 25)) cap = 1ull << 25;
+            chunk0[b] = static_cast<uint32_t>(chunks.size());
+            for (uint32_t j = 0; j < nch; ++j) {
+                chunks.push_back(GzChunk{gz_offsets[i], gz_lengths[i], sym_total, cap, chunk0[b], nch});
+                sym_total += cap;
+            }
+        }
+        const uint32_t nc = static_cast<uint32_t>(chunks.size());
+        // metadata: chunks | starts u64 | len u64 | status u32 | next u32 | isize u32
+        const size_t o_chunks = 0, o_starts = o_chunks + nc * sizeof(GzChunk), o_len = o_starts + nc * 8ull,
+                     o_st = o_len + nc * 8ull, o_next = o_st + nc * 4ull, o_is = o_next + nc * 4ull, meta_b = o_is + nc * 4ull;
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzmeta), &ctx->gzmeta_cap, meta_b + 256);
+        if (rc) return rc;
+        rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzsym), &ctx->gzsym_cap, sym_total * 2 + 256);
+        if (rc) return rc;
+        uint8_t* m = ctx->d_gzmeta;
+        GzChunk* d_chunks = reinterpret_cast<GzChunk*>(m + o_chunks);
+        uint64_t* d_starts = reinterpret_cast<uint64_t*>(m + o_starts);
+        unsigned long long* d_len = reinterpret_cast<unsigned long long*>(m + o_len);
+        uint32_t* d_st = reinterpret_cast<uint32_t*>(m + o_st);
+        uint32_t* d_next = reinterpret_cast<uint32_t*>(m + o_next);
+        uint32_t* d_is = reinterpret_cast<uint32_t*>(m + o_is);
+        uint16_t* d_sym = reinterpret_cast<uint16_t*>(ctx->d_gzsym);
+        VK_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), nc * sizeof(GzChunk), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(vk_gzfind_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_chunks, nc, d_starts);
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(vk_gzchunk_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_sym, d_chunks, nc, d_starts, d_len,
+                           d_st, d_next, d_is);
+        VK_HIP(ctx, hipGetLastError());
+        std::vector<unsigned long long> h_len(nc);
+        std::vector<uint32_t> h_st(nc), h_next(nc), h_is(nc);
+        VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, nc * 8ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_next.data(), d_next, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_is.data(), d_is, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // follow every file's chain of chunks; a file with anything odd in it goes the direct way instead
+        std::vector<GzItem> items;
+        std::vector<uint32_t> first, count, okfile;
+        for (size_t b = 0; b < big.size(); ++b) {
+            const uint32_t i = big[b];
+            const size_t mark = items.size();
+            uint64_t total = 0;
+            uint32_t isum = 0;
+            bool ok = true;
+            uint32_t c = chunk0[b];
+            for (;;) {
+                if (h_st[c] != 0) { ok = false; break; }
+                items.push_back(GzItem{chunks[c].out_off, h_len[c], out_offsets[i] + total});
+                total += h_len[c];
+                isum += h_is[c];
+                const uint32_t nx = h_next[c];
+                if (nx == kGzEnd) break;
+                if (nx <= c || nx >= chunk0[b] + chunks[c].nchunks) { ok = false; break; }
+                c = nx;
+            }
+            if (ok && isum != static_cast<uint32_t>(total)) ok = false;  // the members' size words do not add up to the text
+            if (ok && total > out_caps[i]) {  // e.g. several members and a caller who knew only the last one's size
+                status[i] = VK_GZ_OVERFLOW;
+                items.resize(mark);
+                continue;
+            }
+            if (!ok) {
+                items.resize(mark);
+                direct.push_back(i);
+                continue;
+            }
+            first.push_back(static_cast<uint32_t>(mark));
+            count.push_back(static_cast<uint32_t>(items.size() - mark));
+            okfile.push_back(i);
+            out_lengths[i] = total;
+        }
+        if (!okfile.empty()) {
+            const uint32_t ni = static_cast<uint32_t>(items.size()), nf = static_cast<uint32_t>(okfile.size());
+            const size_t o_items = 0, o_first = o_items + ni * sizeof(GzItem), o_count = o_first + nf * 4ull,
+                         tail_b = o_count + nf * 4ull;
+            // the chunk metadata has been read back: its buffer now carries the items
+            rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzmeta), &ctx->gzmeta_cap, tail_b + 256);
+            if (rc) return rc;
+            rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzwin), &ctx->gzwin_cap, static_cast<size_t>(ni) * 32768 + 256);
+            if (rc) return rc;
+            m = ctx->d_gzmeta;
+            GzItem* d_items = reinterpret_cast<GzItem*>(m + o_items);
+            uint32_t* d_first = reinterpret_cast<uint32_t*>(m + o_first);
+            uint32_t* d_count = reinterpret_cast<uint32_t*>(m + o_count);
+            VK_HIP(ctx, hipMemcpyAsync(d_items, items.data(), ni * sizeof(GzItem), hipMemcpyHostToDevice, ctx->stream));
+            VK_HIP(ctx, hipMemcpyAsync(d_first, first.data(), nf * 4ull, hipMemcpyHostToDevice, ctx->stream));
+            VK_HIP(ctx, hipMemcpyAsync(d_count, count.data(), nf * 4ull, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(vk_gzwin_kernel, dim3(nf), dim3(1024), 0, ctx->stream, reinterpret_cast<uint16_t*>(ctx->d_gzsym),
+                               d_items, d_first, d_count, ctx->d_gzwin);
+            VK_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(vk_gzfinal_kernel, dim3(32, ni), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<uint16_t*>(ctx->d_gzsym), d_items, ni, ctx->d_gzwin, out);
+            VK_HIP(ctx, hipGetLastError());
+            VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (items / first / count are read by the kernels)
+        }
+    }
+
+    // ---- small files, and large ones the chunked path gave up on: one wavefront per file -----------
+    if (!direct.empty()) {
+        const uint32_t nd = static_cast<uint32_t>(direct.size());
+        const size_t jobs_b = static_cast<size_t>(nd) * sizeof(GzJob), len_b = static_cast<size_t>(nd) * 8,
+                     st_b = static_cast<size_t>(nd) * 4;
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + st_b);
+        if (rc) return rc;
+        std::vector<GzJob> jobs(nd);
+        for (uint32_t j = 0; j < nd; ++j) {
+            const uint32_t i = direct[j];
+            jobs[j] = GzJob{gz_offsets[i], gz_lengths[i], out_offsets[i], out_caps[i]};
+        }
+        GzJob* d_jobs = reinterpret_cast<GzJob*>(ctx->d_gzjobs);
+        unsigned long long* d_len = reinterpret_cast<unsigned long long*>(ctx->d_gzjobs + jobs_b);
+        uint32_t* d_st = reinterpret_cast<uint32_t*>(ctx->d_gzjobs + jobs_b + len_b);
+        VK_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs_b, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(vk_inflate_kernel, dim3(nd), dim3(64), 0, ctx->stream, gz, out, d_jobs, nd, d_len, d_st);
+        VK_HIP(ctx, hipGetLastError());
+        std::vector<unsigned long long> h_len(nd);
+        std::vector<uint32_t> h_st(nd);
+        VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, len_b, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, st_b, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also keeps `jobs` alive until the copy has read it)
+        for (uint32_t j = 0; j < nd; ++j) {
+            out_lengths[direct[j]] = h_len[j];
+            status[direct[j]] = h_st[j];
+        }
+    }
     return VK_OK;
 }
 

@@ -191,18 +191,27 @@ def end_to_end(eng, args):
         gz_bytes = sum(p.stat().st_size for p in gz)
         del host
         bases = nfiles * reads * args.readlen
-        for name, files, moved in (("plain_text", plain, text_bytes), ("fq_gz", gz, gz_bytes)):
+        # (batches: 2 GiB of text for plain files, so that reading the next batch overlaps the copy of this one;
+        # 16 GiB for gzip files, whose staging is cheap and whose inflate wants many files in flight)
+        for name, files, moved, bb in (("plain_text", plain, text_bytes, 2 << 30), ("fq_gz", gz, gz_bytes, 16 << 30)):
             dst = tmp / ("img_" + name)
-            pipeline.fastqs_to_images(files[:2], tmp / ("warm_" + name), k=args.k, mapping_code=args.mapping,
-                                      io_threads=threads, engine=eng)
+            # one untimed pass first: staging buffers and device workspaces are allocated once per process
+            pipeline.fastqs_to_images(files, tmp / ("warm_" + name), k=args.k, mapping_code=args.mapping,
+                                      io_threads=threads, engine=eng, batch_bytes=bb)
             t0 = time.perf_counter()
             stats = pipeline.fastqs_to_images(files, dst, k=args.k, mapping_code=args.mapping, io_threads=threads,
-                                              engine=eng, batch_bytes=2 << 30)
+                                              engine=eng, batch_bytes=bb)
             dt = time.perf_counter() - t0
             ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
             out[name] = {"seconds": dt, "gbases_per_s": bases / dt / 1e9, "files_per_s": nfiles / dt,
                          "file_bytes": moved, "file_gb_per_s": moved / dt / 1e9, "text_gb_per_s": text_bytes / dt / 1e9,
-                         "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png")))}
+                         "batch_bytes": bb, "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png")))}
+        # the two routes must give the same images
+        same = 0
+        for p in sorted((tmp / "img_plain_text").rglob("*.png")):
+            q = tmp / "img_fq_gz" / p.name
+            same += int(q.is_file() and q.read_bytes() == p.read_bytes())
+        out["gz_pngs_identical_to_plain"] = same == nfiles
         # the link itself, for scale: one pinned 1 GiB buffer, host to device
         pin = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
         dev = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
@@ -213,8 +222,8 @@ def end_to_end(eng, args):
             dev.copy_(pin, non_blocking=True)
         torch.cuda.synchronize()
         out["pcie_h2d_gb_per_s_pinned_1GiB"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
-        out["note"] = ("files -> PNGs, page cache warm, one GPU; .fq.gz files are inflated on the host "
-                       "(zlib, io_threads threads) before the H2D copy")
+        out["note"] = ("files -> PNGs, page cache warm, one GPU; .fq.gz files cross PCIe compressed and are "
+                       "inflated in HBM (vk_inflate_device)")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

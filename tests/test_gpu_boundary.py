@@ -214,7 +214,7 @@ def test_bench_script_runs_end_to_end(tmp_path):
     e = d["end_to_end"]
     for leg in ("plain_text", "fq_gz"):
         assert e[leg]["all_files_ok"] and e[leg]["pngs"] == 6 and e[leg]["gbases_per_s"] > 0
-    assert e["fq_gz"]["file_bytes"] < e["plain_text"]["file_bytes"]
+    assert e["fq_gz"]["file_bytes"] < e["plain_text"]["file_bytes"] and e["gz_pngs_identical_to_plain"]
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():

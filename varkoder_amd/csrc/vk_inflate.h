@@ -30,14 +30,22 @@ constexpr int kLitRoot = 11, kDistRoot = 9;
 constexpr uint32_t kRing = 512;          // token ring (resolved when fewer than 64 slots are free)
 constexpr uint32_t kLongMatch = 24;      // matches at least this long are copied by the whole wave
 
-// table entry: bits 0-3 code length (0 = no such code, 15 = longer than the root: finish bit by bit),
-//              bits 4-7 extra bits, bits 8-9 kind (0 literal, 1 length, 2 end of block), bits 16-31 value
+// table entry: bits 0-3 bits consumed (0 = no such code, 15 = a code longer than the root: finish bit by bit),
+//              bits 4-5 kind (0 literals, 1 length / distance, 2 end of block, 3 invalid);
+//   literals:  bits 6-7 how many (1..3) minus one, bits 8-31 the bytes, first one lowest;
+//   length / distance: bits 6-9 extra bits, bits 16-31 base value.
+// Literal entries hold up to three literals: FASTQ bases have 2-3 bit codes, and every token costs a
+// hop of the chain walk and a ring slot.
 constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindBad = 3;
+constexpr uint32_t kBadEntry = kKindBad << 4;
+__device__ __forceinline__ uint32_t gz_lit_entry(uint32_t sym) { return (sym << 8) | (kKindLit << 4); }
+__device__ __forceinline__ uint32_t gz_len_entry(uint32_t base, uint32_t extra) { return (base << 16) | (extra << 6) | (kKindLen << 4); }
 
 struct GzLds {
     uint32_t lit[1 << kLitRoot];
     uint32_t dst[1 << kDistRoot];
-    uint32_t ring[kRing];        // literal: byte; match: 0x80000000 | dist << 9 | len
+    uint32_t ring[kRing];        // literals: bytes | (count - 1) << 24; match: 0x80000000 | dist << 9 | len
+    uint32_t stage[512];         // 2 KiB of the compressed stream around the decoding position
     uint16_t lit_sym[288];       // symbols ordered by (code length, symbol): canonical decoding of long codes
     uint16_t dst_sym[32];
     uint16_t lit_cnt[16], dst_cnt[16];
@@ -105,7 +113,7 @@ __device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint1
         used += count[l];
     }
     if (left > 0 && (LITLEN || used > 1)) return false;  // incomplete
-    for (uint32_t i = lane; i < (1u << ROOT); i += 64) table[i] = kKindBad << 8;
+    for (uint32_t i = lane; i < (1u << ROOT); i += 64) table[i] = kBadEntry;
     if (lane < 16) cnt[lane] = static_cast<uint16_t>(lane ? count[lane] : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -126,24 +134,61 @@ __device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint1
             const uint32_t c = fl + rank;
             uint32_t entry;
             if (LITLEN) {
-                if (s < 256) entry = (s << 16) | (kKindLit << 8);
-                else if (s == 256) entry = kKindEob << 8;
-                else if (s < 286) entry = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
-                else entry = kKindBad << 8;  // 286, 287 never occur in valid data
+                if (s < 256) entry = gz_lit_entry(s);
+                else if (s == 256) entry = kKindEob << 4;
+                else if (s < 286) entry = gz_len_entry(kLenBase[s - 257], kLenExtra[s - 257]);
+                else entry = kBadEntry;  // 286, 287 never occur in valid data
             } else {
-                entry = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
-                               : (kKindBad << 8);
+                entry = s < 30 ? gz_len_entry(kDistBase[s], kDistExtra[s]) : kBadEntry;
             }
             if (l <= static_cast<uint32_t>(ROOT)) {
                 entry |= l;
                 for (uint32_t idx = gz_rev(c, l); idx < (1u << ROOT); idx += 1u << l) table[idx] = entry;
             } else {
-                table[gz_rev(c, l) & ((1u << ROOT) - 1u)] = 15u | (kKindBad << 8);  // finish bit by bit
+                table[gz_rev(c, l) & ((1u << ROOT) - 1u)] = 15u | kBadEntry;  // finish bit by bit
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (LITLEN) {
+        // Second and third literals: entry i starts with a literal of L1 bits; if the bits left over, i >> L1,
+        // select literals that need at most ROOT - L1 bits, they go into the same entry.  The entry consulted
+        // sits at a lower index (i >> L1 < i for i > 0), so the table is upgraded in place from the bottom up,
+        // range [2^(t-1), 2^t) after the ranges below it; entry 0 refers to itself and goes first.
+        if (lane == 0) {
+            const uint32_t e = table[0], L1 = e & 15u;
+            if (((e >> 4) & 3u) == kKindLit && L1 != 0u) {
+                const uint32_t b = (e >> 8) & 0xFFu;
+                if (3u * L1 <= static_cast<uint32_t>(ROOT)) table[0] = (3u * L1) | (kKindLit << 4) | (2u << 6) | (b << 8) | (b << 16) | (b << 24);
+                else if (2u * L1 <= static_cast<uint32_t>(ROOT)) table[0] = (2u * L1) | (kKindLit << 4) | (1u << 6) | (b << 8) | (b << 16);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int top = 1; top <= ROOT; ++top) {
+            const uint32_t lo = 1u << (top - 1), hi = 1u << top;
+            for (uint32_t i = lo + lane; i < hi; i += 64) {
+                uint32_t e = table[i];
+                uint32_t L1 = e & 15u;
+                if (((e >> 4) & 3u) == kKindLit && L1 != 0u && L1 < static_cast<uint32_t>(ROOT)) {
+                    const uint32_t e2 = table[i >> L1];
+                    const uint32_t L2 = e2 & 15u;
+                    // e2 may hold several literals already; all the bits it consumes must be real bits of i
+                    if (((e2 >> 4) & 3u) == kKindLit && L2 != 0u && L1 + L2 <= static_cast<uint32_t>(ROOT)) {
+                        const uint32_t n2 = ((e2 >> 6) & 3u) + 1u;
+                        if (n2 <= 2u) {
+                            // bytes of e2 behind ours, count 1 + n2
+                            e = (L1 + L2) | (kKindLit << 4) | (n2 << 6) | (e & 0xFF00u) | ((e2 & 0xFFFF00u) << 8);
+                            table[i] = e;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     return true;
 }
 
@@ -307,6 +352,8 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     uint32_t next = kGzEnd;
     uint32_t isize_sum = 0;      // sum (mod 2^32) of the ISIZE words of the member trailers passed: the host checks it against the text
     uint32_t jn = my_chunk + 1;  // SYM: the next chunk whose block start has not been passed yet
+    uint64_t stage_base = 0;     // byte offset of L.stage[0] in the stream
+    bool staged = false;
     // how far back a distance may reach at output offset `off`: to the start of the gzip member, which in
     // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
     bool window_open = SYM && !at_header;
@@ -335,7 +382,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
             const uint32_t tok = t < nring ? L.ring[t] : 0u;
             const bool live = t < nring;
             const bool is_match = (tok >> 31) != 0u;
-            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
+            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : ((tok >> 24) & 3u) + 1u);
             const uint32_t dist = (tok >> 9) & 0xFFFFu;
             // inclusive prefix sum of len over the wave
             uint32_t incl = len;
@@ -369,6 +416,8 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                 // short tokens: one lane each
                 if (mine && !is_match) {
                     store_elem(off, tok & 0xFFu);
+                    if (len > 1u) store_elem(off + 1, (tok >> 8) & 0xFFu);
+                    if (len > 2u) store_elem(off + 2, (tok >> 16) & 0xFFu);
                 } else if (mine && len < kLongMatch) {
                     for (uint32_t i = 0; i < len; ++i) store_elem(off + i, load_elem(src0 + (i < dist ? i : i % dist)));
                 }
@@ -487,23 +536,51 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                         resolve();
                         if (st) break;
                     }
+                    // the compressed bytes around pos come from LDS (refilled every KiB of progress)
+                    if ((pos >> 3) - stage_base >= 1024u || !staged) {
+                        stage_base = (pos >> 3) & ~3ull;
+                        for (uint32_t q = lane; q < 128; q += 64) {  // 2 KiB = 128 x 16 bytes
+                            const uint64_t b = stage_base + 16ull * q;
+                            uint4 v = make_uint4(0, 0, 0, 0);
+                            if (b + 16 <= nbytes) {
+                                __builtin_memcpy(&v, in + b, 16);
+                            } else {
+                                uint32_t t[4] = {0, 0, 0, 0};
+                                for (int i = 0; i < 16; ++i)
+                                    if (b + i < nbytes) t[i >> 2] |= static_cast<uint32_t>(in[b + i]) << (8 * (i & 3));
+                                v = make_uint4(t[0], t[1], t[2], t[3]);
+                            }
+                            reinterpret_cast<uint4*>(L.stage)[q] = v;
+                        }
+                        staged = true;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                     // every lane: the token that would start at pos + lane
-                    const uint64_t ww = gz_peek(in, nbytes, pos + lane);
+                    uint64_t ww;
+                    {
+                        const uint64_t p = pos + lane;
+                        const uint32_t rel = static_cast<uint32_t>((p >> 3) - stage_base);  // < 1024 + 8
+                        const uint32_t d = rel >> 2, sh = (rel & 3u) * 8u + static_cast<uint32_t>(p & 7u);  // sh < 32
+                        const uint32_t w0 = L.stage[d], w1 = L.stage[d + 1], w2 = L.stage[d + 2];
+                        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                        ww = (static_cast<uint64_t>(hi) << 32) | lo;
+                    }
                     uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
                     uint32_t used = e & 15u;
                     if (used == 15u) {  // a long code (rare)
                         uint32_t l;
                         const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
                         used = l;
-                        if (s < 256) e = (s << 16) | (kKindLit << 8);
-                        else if (s == 256) e = kKindEob << 8;
-                        else if (s < 286) e = (static_cast<uint32_t>(kLenBase[s - 257]) << 16) | (kKindLen << 8) | (static_cast<uint32_t>(kLenExtra[s - 257]) << 4);
-                        else e = kKindBad << 8;
+                        if (s < 256) e = gz_lit_entry(s);
+                        else if (s == 256) e = kKindEob << 4;
+                        else if (s < 286) e = gz_len_entry(kLenBase[s - 257], kLenExtra[s - 257]);
+                        else e = kBadEntry;
                     }
-                    uint32_t kind = (e >> 8) & 3u;
-                    uint32_t tok = e >> 16;  // literal byte
+                    uint32_t kind = (e >> 4) & 3u;
+                    uint32_t tok = ((e >> 8) & 0xFFFFFFu) | (((e >> 6) & 3u) << 24);  // literals: bytes | (count - 1) << 24
                     if (kind == kKindLen) {
-                        const uint32_t xb = (e >> 4) & 15u;
+                        const uint32_t xb = (e >> 6) & 15u;
                         const uint32_t len = (e >> 16) + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
                         used += xb;
                         const uint64_t w2 = ww >> used;
@@ -513,35 +590,35 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                             uint32_t l;
                             const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
                             dl = l;
-                            d = s < 30 ? (static_cast<uint32_t>(kDistBase[s]) << 16) | (static_cast<uint32_t>(kDistExtra[s]) << 4) | (kKindLen << 8)
-                                       : (kKindBad << 8);
+                            d = s < 30 ? gz_len_entry(kDistBase[s], kDistExtra[s]) : kBadEntry;
                         }
-                        if (((d >> 8) & 3u) != kKindLen || dl == 0u) {
+                        if (((d >> 4) & 3u) != kKindLen || dl == 0u) {
                             kind = kKindBad;
                         } else {
-                            const uint32_t dxb = (d >> 4) & 15u;
+                            const uint32_t dxb = (d >> 6) & 15u;
                             const uint32_t dist = (d >> 16) + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
                             used += dl + dxb;
                             tok = 0x80000000u | (dist << 9) | len;
                         }
                     }
                     if (used == 0u) kind = kKindBad;
-                    // the true chain through the 64 answers
+                    // the true chain through the 64 answers (kind and bits consumed travel in one register)
+                    const uint32_t ku = kind | (used << 2);
                     unsigned long long chain = 0;
                     uint32_t at = 0, ntok = 0;
                     bool bad = false;
                     while (at < 64) {
-                        const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
+                        const uint32_t x = __builtin_amdgcn_readlane(static_cast<int>(ku), at);
+                        const uint32_t k = x & 3u;
                         if (k == kKindBad) { bad = true; break; }
-                        const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
                         if (k == kKindEob) {
                             eob = true;
-                            at += u;
+                            at += x >> 2;
                             break;
                         }
                         chain |= 1ull << at;
                         ++ntok;
-                        at += u;
+                        at += x >> 2;
                     }
                     if (bad) { st |= kGzBadData; break; }
                     if ((chain >> lane) & 1ull)

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvkimg_hip.so")
+LIB_PATH = os.environ.get("VKIMG_LIB") or os.path.join(HERE, "libvkimg_hip.so")  # (VKIMG_LIB: A/B timing of experimental builds)
 
 VK_OK, VK_EINVAL, VK_EHIP, VK_ENOMAP, VK_EFORMAT, VK_ENOMEM = 0, 1, 2, 3, 4, 5
 VK_ST_BAD_START, VK_ST_BAD_PHASE = 1, 2

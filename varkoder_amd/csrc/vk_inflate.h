@@ -27,31 +27,62 @@
 namespace {
 
 constexpr int kLitRoot = 11, kDistRoot = 9;
-constexpr uint32_t kRing = 512;          // token ring (resolved when fewer than 64 slots are free)
+constexpr uint32_t kRing = 256;          // token ring (resolved when fewer than 64 slots are free)
 constexpr uint32_t kLongMatch = 24;      // matches at least this long are copied by the whole wave
 
-// table entry: bits 0-3 bits consumed (0 = no such code, 15 = a code longer than the root: finish bit by bit),
-//              bits 4-5 kind (0 literals, 1 length / distance, 2 end of block, 3 invalid);
-//   literals:  bits 6-7 how many (1..3) minus one, bits 8-31 the bytes, first one lowest;
-//   length / distance: bits 6-9 extra bits, bits 16-31 base value.
-// Literal entries hold up to three literals: FASTQ bases have 2-3 bit codes, and every token costs a
-// hop of the chain walk and a ring slot.
+// Table entry (16 bits: the tables are what limits the wavefronts a CU can hold, and a lone wavefront
+// issues an instruction every ~4 ns -- throughput comes from many of them):
+//   bits 0-3 code length (0 = no such code, 15 = longer than the root: finish bit by bit),
+//   bits 4-5 kind (0 literal, 1 length / distance, 2 end of block, 3 invalid),
+//   bits 6-15 literal byte, or the index of the length (0..28) / distance (0..29) symbol, whose
+//   base value and extra bits follow from the index by arithmetic (gz_len_of / gz_dist_of).
 constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindBad = 3;
 constexpr uint32_t kBadEntry = kKindBad << 4;
-__device__ __forceinline__ uint32_t gz_lit_entry(uint32_t sym) { return (sym << 8) | (kKindLit << 4); }
-__device__ __forceinline__ uint32_t gz_len_entry(uint32_t base, uint32_t extra) { return (base << 16) | (extra << 6) | (kKindLen << 4); }
 
 struct GzLds {
-    uint32_t lit[1 << kLitRoot];
-    uint32_t dst[1 << kDistRoot];
-    uint32_t ring[kRing];        // literals: bytes | (count - 1) << 24; match: 0x80000000 | dist << 9 | len
-    uint32_t stage[512];         // 2 KiB of the compressed stream around the decoding position
+    uint16_t lit[1 << kLitRoot];
+    uint16_t dst[1 << kDistRoot];
+    uint32_t ring[kRing];        // literal: byte; match: 0x80000000 | dist << 9 | len
     uint16_t lit_sym[288];       // symbols ordered by (code length, symbol): canonical decoding of long codes
     uint16_t dst_sym[32];
     uint16_t lit_cnt[16], dst_cnt[16];
     uint8_t lens[320];           // code lengths of the block being set up
     uint8_t pre[128];            // code-length code: 7-bit lookup, sym | len << 5
 };
+
+// length symbol 257 + i: base length and extra bits (RFC 1951 3.2.5), i = 0..28
+__device__ __forceinline__ void gz_len_of(uint32_t i, uint32_t& base, uint32_t& extra) {
+    if (i < 8u) {
+        base = 3u + i;
+        extra = 0u;
+    } else if (i == 28u) {
+        base = 258u;
+        extra = 0u;
+    } else {
+        extra = (i >> 2) - 1u;
+        base = ((4u + (i & 3u)) << extra) + 3u;
+    }
+}
+
+// distance symbol s: base distance and extra bits, s = 0..29
+__device__ __forceinline__ void gz_dist_of(uint32_t s, uint32_t& base, uint32_t& extra) {
+    if (s < 4u) {
+        base = s + 1u;
+        extra = 0u;
+    } else {
+        extra = (s >> 1) - 1u;
+        base = ((2u + (s & 1u)) << extra) + 1u;
+    }
+}
+
+// entry of a literal/length symbol (0..285; 286, 287 are invalid) without its code length
+__device__ __forceinline__ uint32_t gz_lit_entry(uint32_t s) {
+    if (s < 256u) return (s << 6) | (kKindLit << 4);
+    if (s == 256u) return kKindEob << 4;
+    if (s < 286u) return ((s - 257u) << 6) | (kKindLen << 4);
+    return kBadEntry;
+}
+__device__ __forceinline__ uint32_t gz_dist_entry(uint32_t s) { return s < 30u ? (s << 6) | (kKindLen << 4) : kBadEntry; }
 
 __device__ __forceinline__ uint32_t gz_rev(uint32_t code, uint32_t len) { return __brev(code) >> (32u - len); }
 
@@ -73,19 +104,13 @@ __device__ __forceinline__ uint64_t gz_peek(const uint8_t* in, uint64_t nbytes, 
     return s ? (lo >> s) | (hi << (64u - s)) : lo;
 }
 
-__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59,
-                                      67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769,
-                                       1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Build the lookup table of one alphabet from code lengths lens[0..n): returns false if the set is
 // over-subscribed, or incomplete (allowed only for a distance alphabet with at most one code, as zlib does).
 // Runs on the whole wave (lane = threadIdx.x & 63); lens, table, sym, cnt are in LDS.
 template <bool LITLEN>
-__device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint16_t* sym, uint16_t* cnt, int lane) {
+__device__ bool gz_build(const uint8_t* lens, uint32_t n, uint16_t* table, uint16_t* sym, uint16_t* cnt, int lane) {
     constexpr int ROOT = LITLEN ? kLitRoot : kDistRoot;
     // canonical codes: counts per length, first code per length (every lane computes the same scalars)
     uint32_t count[16];
@@ -113,7 +138,7 @@ __device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint1
         used += count[l];
     }
     if (left > 0 && (LITLEN || used > 1)) return false;  // incomplete
-    for (uint32_t i = lane; i < (1u << ROOT); i += 64) table[i] = kBadEntry;
+    for (uint32_t i = lane; i < (1u << ROOT); i += 64) table[i] = static_cast<uint16_t>(kBadEntry);
     if (lane < 16) cnt[lane] = static_cast<uint16_t>(lane ? count[lane] : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -132,63 +157,17 @@ __device__ bool gz_build(const uint8_t* lens, uint32_t n, uint32_t* table, uint1
             }
             sym[ol + rank] = static_cast<uint16_t>(s);
             const uint32_t c = fl + rank;
-            uint32_t entry;
-            if (LITLEN) {
-                if (s < 256) entry = gz_lit_entry(s);
-                else if (s == 256) entry = kKindEob << 4;
-                else if (s < 286) entry = gz_len_entry(kLenBase[s - 257], kLenExtra[s - 257]);
-                else entry = kBadEntry;  // 286, 287 never occur in valid data
-            } else {
-                entry = s < 30 ? gz_len_entry(kDistBase[s], kDistExtra[s]) : kBadEntry;
-            }
+            uint32_t entry = LITLEN ? gz_lit_entry(s) : gz_dist_entry(s);
             if (l <= static_cast<uint32_t>(ROOT)) {
                 entry |= l;
-                for (uint32_t idx = gz_rev(c, l); idx < (1u << ROOT); idx += 1u << l) table[idx] = entry;
+                for (uint32_t idx = gz_rev(c, l); idx < (1u << ROOT); idx += 1u << l) table[idx] = static_cast<uint16_t>(entry);
             } else {
-                table[gz_rev(c, l) & ((1u << ROOT) - 1u)] = 15u | kBadEntry;  // finish bit by bit
+                table[gz_rev(c, l) & ((1u << ROOT) - 1u)] = static_cast<uint16_t>(15u | kBadEntry);  // finish bit by bit
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (LITLEN) {
-        // Second and third literals: entry i starts with a literal of L1 bits; if the bits left over, i >> L1,
-        // select literals that need at most ROOT - L1 bits, they go into the same entry.  The entry consulted
-        // sits at a lower index (i >> L1 < i for i > 0), so the table is upgraded in place from the bottom up,
-        // range [2^(t-1), 2^t) after the ranges below it; entry 0 refers to itself and goes first.
-        if (lane == 0) {
-            const uint32_t e = table[0], L1 = e & 15u;
-            if (((e >> 4) & 3u) == kKindLit && L1 != 0u) {
-                const uint32_t b = (e >> 8) & 0xFFu;
-                if (3u * L1 <= static_cast<uint32_t>(ROOT)) table[0] = (3u * L1) | (kKindLit << 4) | (2u << 6) | (b << 8) | (b << 16) | (b << 24);
-                else if (2u * L1 <= static_cast<uint32_t>(ROOT)) table[0] = (2u * L1) | (kKindLit << 4) | (1u << 6) | (b << 8) | (b << 16);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int top = 1; top <= ROOT; ++top) {
-            const uint32_t lo = 1u << (top - 1), hi = 1u << top;
-            for (uint32_t i = lo + lane; i < hi; i += 64) {
-                uint32_t e = table[i];
-                uint32_t L1 = e & 15u;
-                if (((e >> 4) & 3u) == kKindLit && L1 != 0u && L1 < static_cast<uint32_t>(ROOT)) {
-                    const uint32_t e2 = table[i >> L1];
-                    const uint32_t L2 = e2 & 15u;
-                    // e2 may hold several literals already; all the bits it consumes must be real bits of i
-                    if (((e2 >> 4) & 3u) == kKindLit && L2 != 0u && L1 + L2 <= static_cast<uint32_t>(ROOT)) {
-                        const uint32_t n2 = ((e2 >> 6) & 3u) + 1u;
-                        if (n2 <= 2u) {
-                            // bytes of e2 behind ours, count 1 + n2
-                            e = (L1 + L2) | (kKindLit << 4) | (n2 << 6) | (e & 0xFF00u) | ((e2 & 0xFFFF00u) << 8);
-                            table[i] = e;
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
     return true;
 }
 
@@ -352,8 +331,6 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     uint32_t next = kGzEnd;
     uint32_t isize_sum = 0;      // sum (mod 2^32) of the ISIZE words of the member trailers passed: the host checks it against the text
     uint32_t jn = my_chunk + 1;  // SYM: the next chunk whose block start has not been passed yet
-    uint64_t stage_base = 0;     // byte offset of L.stage[0] in the stream
-    bool staged = false;
     // how far back a distance may reach at output offset `off`: to the start of the gzip member, which in
     // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
     bool window_open = SYM && !at_header;
@@ -382,7 +359,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
             const uint32_t tok = t < nring ? L.ring[t] : 0u;
             const bool live = t < nring;
             const bool is_match = (tok >> 31) != 0u;
-            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : ((tok >> 24) & 3u) + 1u);
+            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
             const uint32_t dist = (tok >> 9) & 0xFFFFu;
             // inclusive prefix sum of len over the wave
             uint32_t incl = len;
@@ -416,8 +393,6 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                 // short tokens: one lane each
                 if (mine && !is_match) {
                     store_elem(off, tok & 0xFFu);
-                    if (len > 1u) store_elem(off + 1, (tok >> 8) & 0xFFu);
-                    if (len > 2u) store_elem(off + 2, (tok >> 16) & 0xFFu);
                 } else if (mine && len < kLongMatch) {
                     for (uint32_t i = 0; i < len; ++i) store_elem(off + i, load_elem(src0 + (i < dist ? i : i % dist)));
                 }
@@ -536,52 +511,22 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                         resolve();
                         if (st) break;
                     }
-                    // the compressed bytes around pos come from LDS (refilled every KiB of progress)
-                    if ((pos >> 3) - stage_base >= 1024u || !staged) {
-                        stage_base = (pos >> 3) & ~3ull;
-                        for (uint32_t q = lane; q < 128; q += 64) {  // 2 KiB = 128 x 16 bytes
-                            const uint64_t b = stage_base + 16ull * q;
-                            uint4 v = make_uint4(0, 0, 0, 0);
-                            if (b + 16 <= nbytes) {
-                                __builtin_memcpy(&v, in + b, 16);
-                            } else {
-                                uint32_t t[4] = {0, 0, 0, 0};
-                                for (int i = 0; i < 16; ++i)
-                                    if (b + i < nbytes) t[i >> 2] |= static_cast<uint32_t>(in[b + i]) << (8 * (i & 3));
-                                v = make_uint4(t[0], t[1], t[2], t[3]);
-                            }
-                            reinterpret_cast<uint4*>(L.stage)[q] = v;
-                        }
-                        staged = true;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
                     // every lane: the token that would start at pos + lane
-                    uint64_t ww;
-                    {
-                        const uint64_t p = pos + lane;
-                        const uint32_t rel = static_cast<uint32_t>((p >> 3) - stage_base);  // < 1024 + 8
-                        const uint32_t d = rel >> 2, sh = (rel & 3u) * 8u + static_cast<uint32_t>(p & 7u);  // sh < 32
-                        const uint32_t w0 = L.stage[d], w1 = L.stage[d + 1], w2 = L.stage[d + 2];
-                        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-                        ww = (static_cast<uint64_t>(hi) << 32) | lo;
-                    }
+                    const uint64_t ww = gz_peek(in, nbytes, pos + lane);
                     uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
                     uint32_t used = e & 15u;
                     if (used == 15u) {  // a long code (rare)
                         uint32_t l;
                         const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
                         used = l;
-                        if (s < 256) e = gz_lit_entry(s);
-                        else if (s == 256) e = kKindEob << 4;
-                        else if (s < 286) e = gz_len_entry(kLenBase[s - 257], kLenExtra[s - 257]);
-                        else e = kBadEntry;
+                        e = gz_lit_entry(s);
                     }
                     uint32_t kind = (e >> 4) & 3u;
-                    uint32_t tok = ((e >> 8) & 0xFFFFFFu) | (((e >> 6) & 3u) << 24);  // literals: bytes | (count - 1) << 24
+                    uint32_t tok = e >> 6;  // literal byte
                     if (kind == kKindLen) {
-                        const uint32_t xb = (e >> 6) & 15u;
-                        const uint32_t len = (e >> 16) + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
+                        uint32_t lbase, xb;
+                        gz_len_of(e >> 6, lbase, xb);
+                        const uint32_t len = lbase + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
                         used += xb;
                         const uint64_t w2 = ww >> used;
                         uint32_t d = L.dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
@@ -590,35 +535,35 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                             uint32_t l;
                             const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
                             dl = l;
-                            d = s < 30 ? gz_len_entry(kDistBase[s], kDistExtra[s]) : kBadEntry;
+                            d = gz_dist_entry(s);
                         }
                         if (((d >> 4) & 3u) != kKindLen || dl == 0u) {
                             kind = kKindBad;
                         } else {
-                            const uint32_t dxb = (d >> 6) & 15u;
-                            const uint32_t dist = (d >> 16) + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
+                            uint32_t dbase, dxb;
+                            gz_dist_of(d >> 6, dbase, dxb);
+                            const uint32_t dist = dbase + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
                             used += dl + dxb;
                             tok = 0x80000000u | (dist << 9) | len;
                         }
                     }
                     if (used == 0u) kind = kKindBad;
-                    // the true chain through the 64 answers (kind and bits consumed travel in one register)
-                    const uint32_t ku = kind | (used << 2);
+                    // the true chain through the 64 answers
                     unsigned long long chain = 0;
                     uint32_t at = 0, ntok = 0;
                     bool bad = false;
                     while (at < 64) {
-                        const uint32_t x = __builtin_amdgcn_readlane(static_cast<int>(ku), at);
-                        const uint32_t k = x & 3u;
+                        const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
                         if (k == kKindBad) { bad = true; break; }
+                        const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
                         if (k == kKindEob) {
                             eob = true;
-                            at += x >> 2;
+                            at += u;
                             break;
                         }
                         chain |= 1ull << at;
                         ++ntok;
-                        at += x >> 2;
+                        at += u;
                     }
                     if (bad) { st |= kGzBadData; break; }
                     if ((chain >> lane) & 1ull)
@@ -743,7 +688,7 @@ __global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict
     if (lane == 0) starts[c] = found;
 }
 
-__global__ __launch_bounds__(64) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
+__global__ __launch_bounds__(64, 6) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
                                                          const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
                                                          const uint64_t* __restrict__ starts,
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,

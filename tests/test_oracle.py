@@ -129,3 +129,23 @@ def test_host_generator_is_stable():
 
 SYNTH_SHA0 = "d3e00ad16ca1838a"
 SYNTH_SHA1 = "c75101c30b4a16db"
+
+
+def test_edge_case_dsk_text_goldens_are_current():
+    """tests/golden/dsk_text_k7/*.txt (oracle/gen_golden_dsktext.py): the dsk2ascii-style dump of every
+    edge case as this build counts it -- kept so that a machine with GATB dsk 2.3.3 can close the
+    'counting parity unpinned' gap with one diff per case."""
+    import os
+
+    from fastq_cases import edge_cases
+    from varkoder_amd import formats
+    gold = os.path.join(os.path.dirname(__file__), "golden", "dsk_text_k7")
+    for name, fq in edge_cases().items():
+        hist, _, st = oracle.count_fastq(fq, 7)
+        assert st == 0
+        with open(os.path.join(gold, name + ".txt")) as f:
+            assert f.read() == formats.dsk_text(hist, 7, "gatb"), name
+        p = os.path.join(gold, name + ".fq")
+        if os.path.exists(p):
+            with open(p, "rb") as f:
+                assert f.read() == fq, name

@@ -194,6 +194,42 @@ def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
         assert np.array_equal(got[1], want2), parts
 
 
+@pytest.mark.parametrize("k", (5, 6, 7))
+def test_low_complexity_runs_switch_the_window_loop_and_stay_exact(engines, k):
+    """Stretches of identical reads (poly-A, short tandem repeats) make the LDS-histogram kernel count
+    whole groups of lanes with one add (windows_lds_hot), entered and left piece by piece as the input
+    changes: histograms equal the oracle's whatever the mix."""
+    from fastq_cases import rec
+    rng = np.random.default_rng(100 + k)
+    recs = []
+    i = 0
+    for block in range(24):
+        kind = block % 4
+        for _ in range(int(rng.integers(40, 400))):
+            if kind == 0:
+                seq = "A" * 150
+            elif kind == 1:
+                seq = "".join(rng.choice(list("ACGT"), size=int(rng.integers(30, 200))))
+            elif kind == 2:
+                seq = ("ACGT" * 40)[: int(rng.integers(60, 160))]
+            else:
+                seq = "T" * 70 + "N" + "G" * 79
+            recs.append(rec(f"r{i}", seq))
+            i += 1
+    fq = b"".join(recs)
+    eng = engines(k)
+    want, nwin, st = oracle.count_fastq(fq, k)
+    assert st == 0
+    dev, offs, lens = eng.upload([fq, b"".join(recs[::-1])])
+    want2 = oracle.count_fastq(b"".join(recs[::-1]), k)[0]
+    for parts in (1, 3):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got = hist.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[0], want), parts
+        assert np.array_equal(got[1], want2), parts
+
+
 @pytest.mark.parametrize("k", (8, 9))
 def test_spill_path_with_a_full_arena_counts_directly(k, monkeypatch):
     """The bucket streams of k = 8, 9 live in a per-sample arena of 4 KiB runs.  With the arena cut

@@ -16,7 +16,7 @@ for k in (7, 9):
     eng = ImageEngine(k=k, mapping="cgr")
     for name, data in (("poly-A", blob), ("ACGT repeat", mixed)):
         fq, offs, lens = eng.upload([data])
-        n = 256
+        n = 512
         o, l = np.repeat(offs, n), np.repeat(lens, n)
         hist = torch.empty((n, 4 ** k), dtype=torch.int32, device="cuda")
         status = torch.empty((n,), dtype=torch.int32, device="cuda")

@@ -204,9 +204,11 @@ __device__ __forceinline__ WaveRange wave_range(uint64_t len, uint32_t parts, ui
 // so the VALU -> SALU hand-over is paid once per block and the addresses are ordinary VALU work
 // the scheduler hoists.  Requires EXEC = all ones on entry (wave_stream runs with the whole wave
 // active) and leaves it so.  lds_base = byte offset of the histogram in LDS.
+// probe_addr / probe_mask: the histogram address and the lane predicate of ONE position of the piece (the
+// last one the loop handles), for the caller's low-complexity test.
 template <int K>
 __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], const uint32_t ok[4],
-                                            uint32_t lds_base) {
+                                            uint32_t lds_base, uint32_t& probe_addr, unsigned long long& probe_mask) {
     static_assert(2 * K + 2 <= 16, "paired extraction needs the field << 2 to fit 16 bits");
     const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
@@ -254,8 +256,99 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
                 : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one)
                 : "memory");
+            if (g == 3 && half == 1) {
+                probe_addr = a[7];
+                probe_mask = m7;
+            }
         }
     }
+}
+
+// Low-complexity input (poly-A tails, short tandem repeats): when most lanes of a position hold the SAME
+// k-mer, their ds_add serialise on one LDS counter (64 lanes: ~15x the cost of a scattered add).  The
+// piece loop therefore probes one position per piece -- do at least 7 of 8 counting lanes agree? -- and
+// while they do, counts the following pieces with this loop instead: per position the lanes that agree
+// with the first counting lane are added by that lane in one go (popcount), up to four such groups, and
+// whatever is left goes one by one.  Exact either way; ordinary reads never enter it.
+__device__ __forceinline__ bool probe_is_hot(uint32_t addr, unsigned long long mask) {
+    if (__builtin_popcountll(mask) < 8) return false;
+    const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(addr), __builtin_ctzll(mask)));
+    const unsigned long long eq = __ballot(addr == first) & mask;
+    return __builtin_popcountll(eq) * 8 >= __builtin_popcountll(mask) * 7;
+}
+
+// Is, in EVERY lane of the wave, every base under a counting window one and the same base?  Then every
+// window of a lane is the same homopolymer k-mer: n = the lane's window count, base = its base (0..3).
+template <int K>
+__device__ __forceinline__ bool piece_is_homopolymer(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], uint32_t& n,
+                                                     uint32_t& base) {
+    // bases covered by a counting window: OK smeared towards lower positions over K - 1 positions
+    uint32_t w[5] = {0u, ok[0], ok[1], ok[2], ok[3]};
+    int cover = 1;
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+        if (cover < K) {
+            const int shp = cover < K - cover ? cover : K - cover;
+            const uint32_t sh = 2u * static_cast<uint32_t>(shp);
+            for (int i = 0; i < 4; ++i) w[i] |= vkl::alignbit(w[i + 1], w[i], sh);
+            w[4] |= w[4] >> sh;
+            cover += shp;
+        }
+    }
+    const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+    uint32_t one0 = 0, zero0 = 0, one1 = 0, zero1 = 0;  // does a covered base have bit 0 (bit 1) set / clear?
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        one0 |= v[i] & w[i];
+        zero0 |= ~v[i] & w[i];
+        one1 |= (v[i] >> 1) & w[i];
+        zero1 |= ~(v[i] >> 1) & w[i];
+    }
+    const bool homo = !((one0 != 0u && zero0 != 0u) || (one1 != 0u && zero1 != 0u));
+    n = vkl::popc(ok[0]) + vkl::popc(ok[1]) + vkl::popc(ok[2]) + vkl::popc(ok[3]);
+    base = (one0 != 0u ? 1u : 0u) | (one1 != 0u ? 2u : 0u);
+    return __all(homo);
+}
+
+template <int K>
+__device__ void windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], uint32_t* hist, int lane,
+                                uint32_t& probe_addr, unsigned long long& probe_mask) {
+    // the probe for the next piece: the window that ends at position 40 of every lane
+    {
+        const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+        constexpr int P = 40, o = 30 + 2 * (P - K + 1), word = o >> 5, sh = o & 31;
+        constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+        const uint32_t x = sh == 0 ? v[word] : vkl::alignbit(v[word + 1 < 5 ? word + 1 : 4], v[word], static_cast<uint32_t>(sh));
+        probe_addr = x & kMask4;
+        probe_mask = __ballot(((ok[P >> 4] >> (2 * (P & 15))) & 1u) != 0u);
+    }
+    // Homopolymer pieces (poly-A / poly-G tails, the common low-complexity case): every window of a lane is
+    // the same k-mer and the lane adds its window count once -- one ds_add per lane and piece instead of 64.
+    {
+        uint32_t n, base;
+        if (piece_is_homopolymer<K>(ch, C, ok, n, base)) {
+            if (n != 0u) atomicAdd(&hist[base * (((1u << (2 * K)) - 1u) / 3u)], n);
+            return;
+        }
+    }
+    vkl::windows<K>(
+        ch, C, ok,
+        [&](uint32_t a4) {  // runs with the counting lanes of one position active
+            unsigned long long left = __ballot(true);
+            bool mine_done = false;
+            for (int it = 0; it < 4 && left; ++it) {
+                const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a4), __builtin_ctzll(left)));
+                const bool same = !mine_done && a4 == first;
+                const unsigned long long eq = __ballot(same);
+                if (same) {
+                    if (lane == __builtin_ctzll(eq)) atomicAdd(&hist[a4 >> 2], static_cast<uint32_t>(__builtin_popcountll(eq)));
+                    mine_done = true;
+                }
+                left &= ~eq;
+            }
+            if (!mine_done) atomicAdd(&hist[a4 >> 2], 1u);
+        },
+        [] {});
 }
 
 // ---- read subsampling (vk_count_sampled_device; vk_lane.h: sample_hash) ------------------------
@@ -566,8 +659,13 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
+        bool hot = false;  // the last piece looked low-complexity: see windows_lds_hot
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
-            windows_lds<K>(ch, C, ok, hist_base);
+            uint32_t pa;
+            unsigned long long pm;
+            if (!hot) windows_lds<K>(ch, C, ok, hist_base, pa, pm);
+            else windows_lds_hot<K>(ch, C, ok, hist, lane, pa, pm);
+            hot = probe_is_hot(pa, pm);
         };
         SubWave sw = {0, 0, 0, 0};
         if constexpr (SUB) {
@@ -854,7 +952,23 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
             npend = 0u;
             maybe_drain(kBlockBytes);  // the queues as the previous piece left them: every full block goes out now
         };
+        // Low-complexity input sends every pair to ONE queue, which overflows into per-pair global atomics.
+        // A piece that saw an overflow makes the next ones try the homopolymer shortcut first: one global
+        // atomic per wavefront and piece (the lanes' window counts summed) instead of thousands.
+        bool hot = false;
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
+            if (hot) {
+                uint32_t n, b;
+                if (piece_is_homopolymer<K>(ch, C, ok, n, b)) {
+#pragma unroll
+                    for (uint32_t bb = 0; bb < 4; ++bb) {  // (a piece can hold poly-A and poly-T reads: one sum per base)
+                        const uint32_t tot = lane_bcast(wave_inclusive_sum(b == bb ? n : 0u), 63);
+                        if (tot != 0u && lane == 0) atomicAdd(&hist_s[pair_reverse(bb * (FMASK / 3u), K)], tot);
+                    }
+                    return;
+                }
+                hot = false;
+            }
             const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -876,6 +990,7 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                             f[j] = both & (1u << (16 * h + 4 * j));
                         }
                         const uint32_t full = append4(x, f);
+                        if (__any(full != 0u)) hot = true;
                         if (full) {  // rare: the queue was full, count the pair directly
 #pragma unroll
                             for (int j = 0; j < 4; ++j)

@@ -157,3 +157,31 @@ def test_inflate_large_files_take_many_wavefronts_and_agree(engines):
     got, status, _, _ = run(eng, [bytes(bad)], caps=[len(texts[1])])
     assert status[0] != 0 or got[0] != texts[1]
     assert status[0] != 0
+
+
+def test_engine_uploads_gzip_files_and_counts_them(engines, tmp_path):
+    """ImageEngine.upload_files: plain and gzip files side by side, a multi-member file whose last size
+    word promises less than it holds (inflated again into a side buffer), and a damaged file that ends
+    up as an empty sample; the histograms of the rest equal the oracle's."""
+    from oracle import oracle
+    eng = engines(7)
+    a = synth.sample_fastq(61, 3000, 150).tobytes()
+    b = synth.sample_fastq(62, 1200, 150, dist=1).tobytes()
+    (tmp_path / "plain.fq").write_bytes(a)
+    (tmp_path / "one.fq.gz").write_bytes(gz(b, 6))
+    (tmp_path / "multi.fq.gz").write_bytes(gz(a, 1) + gz(b, 9))          # last ISIZE = len(b) < len(a + b)
+    bad = bytearray(gz(a, 6))
+    for i in range(300, len(bad) - 8, 211):
+        bad[i] ^= 0x33
+    (tmp_path / "bad.fq.gz").write_bytes(bytes(bad))
+    paths = [tmp_path / "one.fq.gz", tmp_path / "plain.fq", tmp_path / "bad.fq.gz", tmp_path / "multi.fq.gz"]
+    dev, offs, lens = eng.upload_files(paths)
+    host = dev.cpu().numpy()
+    want = [b, a, b"", a + b]
+    for o, n, w in zip(offs, lens, want):
+        assert int(n) == len(w)
+        assert bytes(host[int(o):int(o) + int(n)]) == w
+    hist, status = eng.count(dev, offs, lens)
+    got = hist.cpu().numpy().view(np.uint32)
+    for i, w in enumerate(want):
+        assert np.array_equal(got[i], oracle.count_fastq(w, 7)[0]), i

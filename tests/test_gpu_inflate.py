@@ -185,3 +185,60 @@ def test_engine_uploads_gzip_files_and_counts_them(engines, tmp_path):
     got = hist.cpu().numpy().view(np.uint32)
     for i, w in enumerate(want):
         assert np.array_equal(got[i], oracle.count_fastq(w, 7)[0]), i
+
+
+def test_inflate_fuzz_small_streams(engines):
+    """A few hundred streams from zlib with random level / strategy / window / memLevel over random content
+    kinds, plus streams cut into many flush points (many small blocks, empty stored blocks): all byte-exact."""
+    eng = engines(7)
+    rng = np.random.default_rng(2025)
+    fq = synth.sample_fastq(77, 2000, 150, dist=1).tobytes()
+    files, texts = [], []
+    for i in range(300):
+        kind = int(rng.integers(0, 6))
+        n = int(rng.integers(0, 120_000)) if i % 7 else int(rng.integers(0, 40))
+        if kind == 0:
+            t = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            t = rng.integers(65, 70, size=n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            o = int(rng.integers(0, max(1, len(fq) - n)))
+            t = fq[o:o + n]
+        elif kind == 3:
+            unit = rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+            t = (unit * (n // len(unit) + 1))[:n]
+        elif kind == 4:
+            t = bytes(rng.integers(0, 4, size=n, dtype=np.uint8) * 17 + 33)
+        else:
+            t = b"".join(b"%d\t%x\n" % (j * 7919 % 100003, j) for j in range(n // 12))
+        co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 16 + int(rng.integers(9, 16)), int(rng.integers(1, 10)),
+                              int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])))
+        if i % 5 == 0 and len(t) > 100:      # many blocks: flushes every few hundred bytes
+            z, step = b"", max(50, len(t) // 40)
+            for o in range(0, len(t), step):
+                z += co.compress(t[o:o + step]) + co.flush(zlib.Z_FULL_FLUSH if (o // step) % 3 == 0 else zlib.Z_SYNC_FLUSH)
+            z += co.flush()
+        else:
+            z = co.compress(t) + co.flush()
+        files.append(z)
+        texts.append(t)
+    got, status, _, _ = run(eng, files, caps=[len(t) for t in texts])
+    assert not status.any(), np.flatnonzero(status)
+    for i, (g, t) in enumerate(zip(got, texts)):
+        assert g == t, i
+
+
+def test_inflate_large_files_without_usable_block_starts(engines):
+    """Large files the chunked path cannot split: stored blocks only (no dynamic-codes header anywhere), and a
+    gzip file stored inside another one -- every block header of the inner file sits, byte-aligned, in the
+    outer file's stored blocks, so the finder reports starts that the chunk before never reaches; the decoder
+    must step over them (or hand the file to the one-wavefront kernel)."""
+    eng = engines(7)
+    fq = synth.sample_fastq(88, 30000, 150).tobytes()                  # 9.6 MB
+    inner = gz(fq, 6)                                                  # ~1.6 MB, dozens of dynamic blocks
+    stored_big = gz(fq[:3_000_000], 0)
+    nested = gz(inner, 0)
+    assert len(stored_big) >= 2 * (1 << 18) and len(nested) >= 2 * (1 << 18)
+    got, status, _, _ = run(eng, [stored_big, nested], caps=[3_000_000, len(inner)])
+    assert status.tolist() == [0, 0]
+    assert got[0] == fq[:3_000_000] and got[1] == inner

@@ -51,6 +51,7 @@ extern "C" {
 #define VK_GZ_TRUNCATED 4u     /* the stream ends before its last block / trailer */
 #define VK_GZ_OVERFLOW 8u      /* the text does not fit out_caps[i]: call again with more room */
 #define VK_GZ_BAD_SIZE 16u     /* a member's ISIZE differs from the bytes it inflated to */
+#define VK_GZ_BAD_CRC 32u      /* single-member file: the trailer's CRC-32 is not the CRC-32 of the inflated text */
 
 /* per-sample status bits written by the count stage */
 #define VK_ST_BAD_START 1u     /* first record malformed: no leading '@', or third line not '+' */
@@ -120,7 +121,8 @@ int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* o
  * (single-member files: the little-endian u32 in the file's last four bytes is the text length).
  * Multi-member files and zero padding after the last member are accepted.  out_lengths[i] (host)
  * receives the bytes written and status[i] (host) the VK_GZ_* bits; the call synchronises.
- * Integrity: structure and ISIZE are checked, the CRC-32 of the trailer is not. */
+ * Integrity: structure and every member's ISIZE are checked; the trailer's CRC-32 is verified (on the GPU)
+ * for files that consist of one member, which is what the reference's pipeline writes. */
 int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,
                       uint32_t nfiles, void* d_out, const uint64_t* out_offsets, const uint64_t* out_caps,
                       uint64_t* out_lengths, uint32_t* status);

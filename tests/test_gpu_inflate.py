@@ -242,3 +242,44 @@ def test_inflate_large_files_without_usable_block_starts(engines):
     got, status, _, _ = run(eng, [stored_big, nested], caps=[3_000_000, len(inner)])
     assert status.tolist() == [0, 0]
     assert got[0] == fq[:3_000_000] and got[1] == inner
+
+
+def test_inflate_verifies_the_crc_of_single_member_files(engines):
+    """The trailer's CRC-32 is recomputed on the GPU from the inflated text (segments, GF(2) shift operators)
+    for every file that consists of one member, on the one-wavefront path and on the chunked path alike: a
+    wrong check word, or damage that leaves the stream's structure and size intact (a changed byte inside a
+    stored block), sets VK_GZ_BAD_CRC and nothing else."""
+    eng = engines(7)
+    small = synth.sample_fastq(31, 3000, 150).tobytes()
+    large = synth.sample_fastq(32, 60000, 150, dist=1).tobytes()           # 19 MB: chunked path at level 6
+    texts = [small, large, small[:70001], b"", b"A", b"\0" * 100000, large[: (1 << 16) * 5], large[: (1 << 16) * 5 + 1],
+             small[:1023], small[:1024], small[:1025]]
+    files = [gz(t, 1 + i % 9) for i, t in enumerate(texts)]
+    assert len(files[1]) >= 2 * (1 << 18)
+    got, status, _, _ = run(eng, files)
+    assert status.tolist() == [0] * len(files)
+    assert all(g == t for g, t in zip(got, texts))
+
+    def with_crc(f, delta):
+        word = struct.unpack("<I", f[-8:-4])[0]
+        return f[:-8] + struct.pack("<I", (word + delta) & 0xFFFFFFFF) + f[-4:]
+
+    bad = [with_crc(f, 1 + i) for i, f in enumerate(files)]
+    got, status, _, _ = run(eng, bad)
+    assert status.tolist() == [_capi.VK_GZ_BAD_CRC] * len(bad)
+    assert all(g == t for g, t in zip(got, texts))                         # the text itself is still delivered
+
+    # a changed byte inside stored blocks: only the check word can tell
+    for text in (small, large):
+        f = bytearray(gz(text, 0))
+        assert len(f) > len(text)
+        at = len(f) // 2
+        f[at] ^= 0x01
+        want = bytearray(text)
+        got, status, _, _ = run(eng, [bytes(f)])
+        assert status[0] == _capi.VK_GZ_BAD_CRC, status
+        assert len(got[0]) == len(want) and got[0] != text
+    # several members: sizes are checked, check words are not (documented in include/vkimg.h)
+    two = with_crc(gz(small), 5) + gz(small[:1000])
+    got, status, _, _ = run(eng, [two], caps=[len(small) + 1000])
+    assert status[0] == 0 and got[0] == small + small[:1000]

@@ -32,7 +32,7 @@ def write(i):
 with ThreadPoolExecutor(16) as ex:
     list(ex.map(write, range(nfiles)))
 del host
-for bb in (2 << 30, 8 << 30, 16 << 30):
+for bb in (3 << 30, 5 << 30, 9 << 30, 16 << 30):
     for rep in range(2):
         t0 = time.perf_counter()
         st = pipeline.fastqs_to_images(files, tmp / f"img{bb}_{rep}", k=7, mapping_code="varKode", io_threads=16, engine=eng,

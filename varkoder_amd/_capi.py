@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("VKIMG_LIB") or os.path.join(HERE, "libvkimg_hip.so") 
 
 VK_OK, VK_EINVAL, VK_EHIP, VK_ENOMAP, VK_EFORMAT, VK_ENOMEM = 0, 1, 2, 3, 4, 5
 VK_ST_BAD_START, VK_ST_BAD_PHASE = 1, 2
-VK_GZ_BAD_HEADER, VK_GZ_BAD_DATA, VK_GZ_TRUNCATED, VK_GZ_OVERFLOW, VK_GZ_BAD_SIZE = 1, 2, 4, 8, 16
+VK_GZ_BAD_HEADER, VK_GZ_BAD_DATA, VK_GZ_TRUNCATED, VK_GZ_OVERFLOW, VK_GZ_BAD_SIZE, VK_GZ_BAD_CRC = 1, 2, 4, 8, 16, 32
 
 # every symbol include/vkimg.h declares
 SYMBOLS = ("vk_abi_version", "vk_strerror", "vk_last_hip_error", "vk_ctx_create", "vk_ctx_destroy",

@@ -293,7 +293,7 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
 }
 
 // status bits of one gzip file
-constexpr uint32_t kGzBadHeader = 1u, kGzBadData = 2u, kGzTruncated = 4u, kGzOverflow = 8u, kGzBadSize = 16u;
+constexpr uint32_t kGzBadHeader = 1u, kGzBadData = 2u, kGzTruncated = 4u, kGzOverflow = 8u, kGzBadSize = 16u, kGzBadCrc = 32u;
 
 struct GzJob {
     uint64_t in_off, in_len;     // compressed bytes in the input buffer
@@ -321,7 +321,7 @@ template <bool SYM>
 __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
                         uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
                         uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
-                        uint64_t& out_endbit, uint32_t& out_isize_sum) {
+                        uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc) {
     const int lane = threadIdx.x & 63;
     const uint64_t nbits = nbytes * 8;
     uint64_t pos = start_bit;   // bit position in the input (wave-uniform, like everything that steers the loops)
@@ -330,6 +330,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     uint32_t nring = 0;
     uint32_t next = kGzEnd;
     uint32_t isize_sum = 0;      // sum (mod 2^32) of the ISIZE words of the member trailers passed: the host checks it against the text
+    uint32_t members = 0, last_crc = 0;  // trailers passed, and the CRC-32 word of the last one (checked when the file has one member)
     uint32_t jn = my_chunk + 1;  // SYM: the next chunk whose block start has not been passed yet
     // how far back a distance may reach at output offset `off`: to the start of the gzip member, which in
     // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
@@ -595,6 +596,9 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                                (static_cast<uint32_t>(in[b + 7]) << 24);
         if (!window_open && isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }  // (a member that began in an earlier chunk is checked by the host: sum of the chunks)
         isize_sum += isize;
+        ++members;
+        last_crc = in[b] | (static_cast<uint32_t>(in[b + 1]) << 8) | (static_cast<uint32_t>(in[b + 2]) << 16) |
+                   (static_cast<uint32_t>(in[b + 3]) << 24);
         pos = (b + 8) * 8;
         if (SYM) {  // the starts found inside what this chunk decoded (none, or false ones) are behind us
             while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;
@@ -606,22 +610,27 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     out_next = next;
     out_endbit = pos;
     out_isize_sum = isize_sum;
+    out_members = members;
+    out_crc = last_crc;
 }
 
 __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restrict__ gz, uint8_t* __restrict__ out,
                                                          const GzJob* __restrict__ jobs, uint32_t njobs,
                                                          unsigned long long* __restrict__ out_len,
-                                                         uint32_t* __restrict__ status) {
+                                                         uint32_t* __restrict__ status, uint32_t* __restrict__ members,
+                                                         uint32_t* __restrict__ crc) {
     __shared__ GzLds L;
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
     uint64_t n = 0, endbit = 0;
-    uint32_t st = 0, next = 0, isum = 0;
+    uint32_t st = 0, next = 0, isum = 0, nm = 0, cr = 0;
     gz_wave<false>(L, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
-                   nullptr, 0, 0, n, st, next, endbit, isum);
+                   nullptr, 0, 0, n, st, next, endbit, isum, nm, cr);
     if ((threadIdx.x & 63) == 0) {
         out_len[job] = n;
         status[job] = st;
+        members[job] = nm;
+        crc[job] = cr;
     }
 }
 
@@ -692,26 +701,29 @@ __global__ __launch_bounds__(64, 6) void vk_gzchunk_kernel(const uint8_t* __rest
                                                          const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
                                                          const uint64_t* __restrict__ starts,
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
-                                                         uint32_t* __restrict__ next, uint32_t* __restrict__ isize_sum) {
+                                                         uint32_t* __restrict__ next, uint32_t* __restrict__ isize_sum,
+                                                         uint32_t* __restrict__ members, uint32_t* __restrict__ crc) {
     __shared__ GzLds L;
     const uint32_t c = blockIdx.x;
     if (c >= nchunks_total) return;
     const GzChunk ch = chunks[c];
     const uint32_t j = c - ch.file_chunk0;
     uint64_t n = 0, eb = 0;
-    uint32_t st = 0, nx = kGzEnd, isum = 0;
+    uint32_t st = 0, nx = kGzEnd, isum = 0, nm = 0, cr = 0;
     const uint64_t s0 = starts[c];
     if (s0 == kGzNone) {
         st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
     } else {
         gz_wave<true>(L, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
-                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum);
+                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr);
     }
     if ((threadIdx.x & 63) == 0) {
         out_len[c] = n;
         status[c] = st;
         next[c] = nx == kGzEnd ? kGzEnd : ch.file_chunk0 + nx;
         isize_sum[c] = isum;
+        members[c] = nm;
+        crc[c] = cr;
     }
 }
 
@@ -766,6 +778,129 @@ __global__ __launch_bounds__(256) void vk_gzfinal_kernel(const uint16_t* __restr
         const uint32_t x = e[i];
         out[i] = static_cast<uint8_t>(x < 0x8000u ? x : w[x & 0x7FFFu]);
     }
+}
+
+// ---- CRC-32 of the inflated text ------------------------------------------------------------------
+// gzip's check word is the CRC-32 of the member's text.  It is linear over GF(2) apart from its preset and
+// final inversion, so the text is cut into 64 KiB segments COUNTED FROM ITS END (leading zeros do not change
+// a zero-preset remainder, so the short first segment needs no special case).  A wavefront takes a segment
+// in 16 rows of 4 KiB: a row is read with full lines per load (lane = 16 consecutive bytes), turned in LDS so
+// that lane l owns bytes [64 l, 64 l + 64) of the row, and pushed through the four 256-entry tables of
+// "slicing by 4"; between rows the lane's remainder is advanced over the 4032 bytes that are not its own
+// (operator gz_ops[33]).  The 64 lanes are merged by a tree of "shift by 64 x 2^l bytes" operators (32 x 32
+// bit matrices, gz_ops[n] = the operator for 2^n zero bytes, built on the host as zlib's crc32_combine
+// does), one wave per file folds the segment values, and the host adds the preset's contribution (shift by
+// the text length) and the inversion.
+struct GzCrcJob {
+    uint64_t text_off, text_len;
+    uint32_t seg0, nseg;  // this file's slice of the segment array
+};
+
+__device__ __forceinline__ uint32_t gz_apply(const uint32_t* op, uint32_t v) {  // op x v over GF(2)
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r ^= ((v >> i) & 1u) ? op[i] : 0u;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void vk_crc32_seg_kernel(const uint8_t* __restrict__ text, const GzCrcJob* __restrict__ jobs,
+                                                            uint32_t njobs, const uint32_t* __restrict__ seg_job,
+                                                            uint32_t nseg_total, const uint32_t* __restrict__ ops,
+                                                            uint32_t* __restrict__ seg_crc) {
+    __shared__ uint32_t T[4][256];  // T[n][b]: byte b followed by n zero bytes (the tables of "slicing by 4")
+    __shared__ uint32_t M[7][32];   // operators for 64, 128, ..., 2048 bytes, and for 4032
+    __shared__ uint4 rows[4][256];  // one 4 KiB row per wavefront
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        T[0][threadIdx.x] = c;
+        if (threadIdx.x < 192) M[threadIdx.x >> 5][threadIdx.x & 31] = ops[(6 + (threadIdx.x >> 5)) * 32 + (threadIdx.x & 31)];
+        else if (threadIdx.x < 224) M[6][threadIdx.x & 31] = ops[33 * 32 + (threadIdx.x & 31)];
+        __syncthreads();
+        for (int n = 1; n < 4; ++n) {
+            c = T[0][c & 0xFFu] ^ (c >> 8);
+            T[n][threadIdx.x] = c;
+        }
+    }
+    __syncthreads();
+    const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per segment
+    if (seg >= nseg_total) return;
+    const int lane = threadIdx.x & 63;
+    uint4* row = rows[threadIdx.x >> 6];
+    const GzCrcJob jb = jobs[seg_job[seg]];
+    const uint32_t s = seg - jb.seg0;
+    // segment s of nseg covers text positions [end - (nseg - s) * 64K, ...): may start before the text
+    const long long seg_first = static_cast<long long>(jb.text_len) - static_cast<long long>(jb.nseg - s) * 65536ll;
+    const uint8_t* t = text + jb.text_off;
+    uint32_t c = 0;
+    for (int r = 0; r < 16; ++r) {
+        if (seg_first + 4096ll * (r + 1) <= 0) continue;  // a row that lies before the text (wave-uniform)
+        c = gz_apply(M[6], c);                            // skip the other lanes' 4032 bytes (nothing to skip while c is 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long p = seg_first + 4096ll * r + 1024 * i + 16 * lane;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (p >= 0) {
+                __builtin_memcpy(&v, t + p, 16);
+            } else if (p > -16) {  // the text begins inside these sixteen bytes
+                uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (p + q >= 0) w[q >> 2] |= static_cast<uint32_t>(t[p + q]) << (8 * (q & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            row[i * 64 + lane] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = row[lane * 4 + i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                c ^= w[d];
+                c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the row is rewritten by other lanes next
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        const uint32_t other = __shfl_xor(c, 1 << l);
+        if (lane & (1 << l)) c = gz_apply(M[l], other) ^ c;  // the left neighbour's group, shifted over this group
+    }
+    if (lane == 63) seg_crc[seg] = c;
+}
+
+__global__ __launch_bounds__(64) void vk_crc32_fold_kernel(const GzCrcJob* __restrict__ jobs, uint32_t njobs,
+                                                            const uint32_t* __restrict__ ops, const uint32_t* __restrict__ seg_crc,
+                                                            uint32_t* __restrict__ raw) {
+    __shared__ uint32_t M[7][32];  // operators for 64 KiB x 1, 2, ..., 64
+    const uint32_t j = blockIdx.x;
+    if (j >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 7 * 32; i += 64) M[i >> 5][i & 31] = ops[(16 + (i >> 5)) * 32 + (i & 31)];
+    __syncthreads();
+    const GzCrcJob jb = jobs[j];
+    // 64 segments per step, one per lane, merged by the same tree as inside a segment; the file's segments
+    // are preceded by as many empty ones (remainder 0) as it takes to fill the first step
+    const uint32_t nsteps = (jb.nseg + 63) / 64, pad = nsteps * 64 - jb.nseg;
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < nsteps; ++b) {
+        const uint32_t idx = b * 64 + lane;
+        uint32_t v = idx >= pad ? seg_crc[jb.seg0 + (idx - pad)] : 0u;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) {
+            const uint32_t other = __shfl_xor(v, 1 << l);
+            if (lane & (1 << l)) v = gz_apply(M[l], other) ^ v;
+        }
+        c = gz_apply(M[6], c) ^ __shfl(v, 63);
+    }
+    if (lane == 0) raw[j] = c;
 }
 
 }  // namespace

@@ -74,6 +74,8 @@ struct vk_ctx {
     size_t gzsym_cap = 0;
     uint8_t* d_gzwin = nullptr;   // ... the 32 KiB window every chunk of a chain starts with
     size_t gzwin_cap = 0;
+    uint8_t* d_gzcrc = nullptr;   // ... CRC-32 jobs, operators, segment values
+    size_t gzcrc_cap = 0;
     bool gz_no_chunks = false;    // VKIMG_GZ_NO_CHUNKS=1: every file through the one-wavefront kernel (tests, A/B timing)
     size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
@@ -301,7 +303,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -484,6 +486,85 @@ int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img) {
     return VK_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Operators of the CRC-32 (reflected polynomial 0xEDB88320) over GF(2), as zlib's crc32_combine builds them:
+// op[k] advances a remainder over 2^k zero BYTES; 32 columns each.
+struct GzCrcOps {
+    uint32_t op[34][32];  // [33]: 4032 bytes, the step between a lane's pieces in vk_crc32_seg_kernel
+    GzCrcOps() {
+        uint32_t bit1[32], bit2[32], bit4[32];
+        bit1[0] = 0xEDB88320u;  // one zero bit
+        for (int n = 1; n < 32; ++n) bit1[n] = 1u << (n - 1);
+        square(bit2, bit1);
+        square(bit4, bit2);
+        square(op[0], bit4);  // eight zero bits
+        for (int k = 1; k <= 32; ++k) square(op[k], op[k - 1]);
+        for (int n = 0; n < 32; ++n) op[33][n] = shift(1u << n, 4032);
+    }
+    static uint32_t times(const uint32_t* m, uint32_t v) {
+        uint32_t r = 0;
+        for (int i = 0; v; v >>= 1, ++i)
+            if (v & 1u) r ^= m[i];
+        return r;
+    }
+    static void square(uint32_t* sq, const uint32_t* m) {
+        for (int n = 0; n < 32; ++n) sq[n] = times(m, m[n]);
+    }
+    uint32_t shift(uint32_t v, uint64_t nbytes) const {
+        for (int k = 0; nbytes; nbytes >>= 1, ++k)
+            if (nbytes & 1u) v = times(op[k], v);
+        return v;
+    }
+};
+const GzCrcOps& gz_crc_ops() {
+    static const GzCrcOps ops;
+    return ops;
+}
+
+// CRC-32 of texts resident on the device (vk_inflate.h, "CRC-32 of the inflated text"): crc[i] for every job.
+int gz_text_crc(vk_ctx* ctx, const uint8_t* text, const std::vector<GzCrcJob>& jobs_in, std::vector<uint32_t>& crc) {
+    std::vector<GzCrcJob> jobs = jobs_in;
+    std::vector<uint32_t> seg_job;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        jobs[j].seg0 = static_cast<uint32_t>(seg_job.size());
+        jobs[j].nseg = static_cast<uint32_t>((jobs[j].text_len + 65535) / 65536);
+        seg_job.insert(seg_job.end(), jobs[j].nseg, static_cast<uint32_t>(j));
+    }
+    const uint32_t nj = static_cast<uint32_t>(jobs.size()), ns = static_cast<uint32_t>(seg_job.size());
+    crc.assign(nj, 0u);
+    const GzCrcOps& ops = gz_crc_ops();
+    if (ns != 0) {
+        const size_t o_jobs = 0, o_segjob = o_jobs + nj * sizeof(GzCrcJob), o_ops = o_segjob + ns * 4ull,
+                     o_seg = o_ops + sizeof(ops.op), o_raw = o_seg + ns * 4ull, total = o_raw + nj * 4ull;
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzcrc), &ctx->gzcrc_cap, total + 256);
+        if (rc) return rc;
+        uint8_t* m = ctx->d_gzcrc;
+        VK_HIP(ctx, hipMemcpyAsync(m + o_jobs, jobs.data(), nj * sizeof(GzCrcJob), hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(m + o_segjob, seg_job.data(), ns * 4ull, hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(m + o_ops, ops.op, sizeof(ops.op), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(vk_crc32_seg_kernel, dim3((ns + 3) / 4), dim3(256), 0, ctx->stream, text,
+                           reinterpret_cast<const GzCrcJob*>(m + o_jobs), nj, reinterpret_cast<const uint32_t*>(m + o_segjob), ns,
+                           reinterpret_cast<const uint32_t*>(m + o_ops), reinterpret_cast<uint32_t*>(m + o_seg));
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(vk_crc32_fold_kernel, dim3(nj), dim3(64), 0, ctx->stream, reinterpret_cast<const GzCrcJob*>(m + o_jobs),
+                           nj, reinterpret_cast<const uint32_t*>(m + o_ops), reinterpret_cast<const uint32_t*>(m + o_seg),
+                           reinterpret_cast<uint32_t*>(m + o_raw));
+        VK_HIP(ctx, hipGetLastError());
+        VK_HIP(ctx, hipMemcpyAsync(crc.data(), m + o_raw, nj * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // zero-preset remainder -> CRC-32: the preset 0xFFFFFFFF shifted over the text, and the final inversion
+    for (uint32_t j = 0; j < nj; ++j) crc[j] ^= ops.shift(0xFFFFFFFFu, jobs[j].text_len) ^ 0xFFFFFFFFu;
+    return VK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,
                       uint32_t nfiles, void* d_out, const uint64_t* out_offsets, const uint64_t* out_caps,
                       uint64_t* out_lengths, uint32_t* status) {
@@ -494,6 +575,8 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
     const uint8_t* gz = static_cast<const uint8_t*>(d_gz);
     uint8_t* out = static_cast<uint8_t*>(d_out);
     std::vector<uint32_t> direct;  // files that go through the one-wavefront-per-file kernel
+    std::vector<GzCrcJob> crc_jobs;        // single-member files: their text's CRC-32 is checked against the trailer's
+    std::vector<uint32_t> crc_file, crc_want;
 
     // ---- large files: many wavefronts per file (vk_inflate.h, "the chunked path") ------------------
     std::vector<uint32_t> big;
@@ -524,7 +607,8 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         const uint32_t nc = static_cast<uint32_t>(chunks.size());
         // metadata: chunks | starts u64 | len u64 | status u32 | next u32 | isize u32
         const size_t o_chunks = 0, o_starts = o_chunks + nc * sizeof(GzChunk), o_len = o_starts + nc * 8ull,
-                     o_st = o_len + nc * 8ull, o_next = o_st + nc * 4ull, o_is = o_next + nc * 4ull, meta_b = o_is + nc * 4ull;
+                     o_st = o_len + nc * 8ull, o_next = o_st + nc * 4ull, o_is = o_next + nc * 4ull, o_nm = o_is + nc * 4ull,
+                     o_cr = o_nm + nc * 4ull, meta_b = o_cr + nc * 4ull;
         int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzmeta), &ctx->gzmeta_cap, meta_b + 256);
         if (rc) return rc;
         rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzsym), &ctx->gzsym_cap, sym_total * 2 + 256);
@@ -536,19 +620,23 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         uint32_t* d_st = reinterpret_cast<uint32_t*>(m + o_st);
         uint32_t* d_next = reinterpret_cast<uint32_t*>(m + o_next);
         uint32_t* d_is = reinterpret_cast<uint32_t*>(m + o_is);
+        uint32_t* d_nm = reinterpret_cast<uint32_t*>(m + o_nm);
+        uint32_t* d_cr = reinterpret_cast<uint32_t*>(m + o_cr);
         uint16_t* d_sym = reinterpret_cast<uint16_t*>(ctx->d_gzsym);
         VK_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), nc * sizeof(GzChunk), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(vk_gzfind_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_chunks, nc, d_starts);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(vk_gzchunk_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_sym, d_chunks, nc, d_starts, d_len,
-                           d_st, d_next, d_is);
+                           d_st, d_next, d_is, d_nm, d_cr);
         VK_HIP(ctx, hipGetLastError());
         std::vector<unsigned long long> h_len(nc);
-        std::vector<uint32_t> h_st(nc), h_next(nc), h_is(nc);
+        std::vector<uint32_t> h_st(nc), h_next(nc), h_is(nc), h_nm(nc), h_cr(nc);
         VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, nc * 8ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_next.data(), d_next, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_is.data(), d_is, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_nm.data(), d_nm, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_cr.data(), d_cr, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         // follow every file's chain of chunks; a file with anything odd in it goes the direct way instead
         std::vector<GzItem> items;
@@ -557,7 +645,7 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             const uint32_t i = big[b];
             const size_t mark = items.size();
             uint64_t total = 0;
-            uint32_t isum = 0;
+            uint32_t isum = 0, nmem = 0, lastcrc = 0;
             bool ok = true;
             uint32_t c = chunk0[b];
             for (;;) {
@@ -565,6 +653,10 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
                 items.push_back(GzItem{chunks[c].out_off, h_len[c], out_offsets[i] + total});
                 total += h_len[c];
                 isum += h_is[c];
+                if (h_nm[c]) {
+                    nmem += h_nm[c];
+                    lastcrc = h_cr[c];
+                }
                 const uint32_t nx = h_next[c];
                 if (nx == kGzEnd) break;
                 if (nx <= c || nx >= chunk0[b] + chunks[c].nchunks) { ok = false; break; }
@@ -585,6 +677,7 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             count.push_back(static_cast<uint32_t>(items.size() - mark));
             okfile.push_back(i);
             out_lengths[i] = total;
+            if (nmem == 1) crc_jobs.push_back(GzCrcJob{out_offsets[i], total, 0, 0}), crc_file.push_back(i), crc_want.push_back(lastcrc);
         }
         if (!okfile.empty()) {
             const uint32_t ni = static_cast<uint32_t>(items.size()), nf = static_cast<uint32_t>(okfile.size());
@@ -617,7 +710,7 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         const uint32_t nd = static_cast<uint32_t>(direct.size());
         const size_t jobs_b = static_cast<size_t>(nd) * sizeof(GzJob), len_b = static_cast<size_t>(nd) * 8,
                      st_b = static_cast<size_t>(nd) * 4;
-        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + st_b);
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + 3 * st_b);
         if (rc) return rc;
         std::vector<GzJob> jobs(nd);
         for (uint32_t j = 0; j < nd; ++j) {
@@ -627,18 +720,31 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         GzJob* d_jobs = reinterpret_cast<GzJob*>(ctx->d_gzjobs);
         unsigned long long* d_len = reinterpret_cast<unsigned long long*>(ctx->d_gzjobs + jobs_b);
         uint32_t* d_st = reinterpret_cast<uint32_t*>(ctx->d_gzjobs + jobs_b + len_b);
+        uint32_t* d_nm = d_st + nd;
+        uint32_t* d_cr = d_nm + nd;
         VK_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs_b, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(vk_inflate_kernel, dim3(nd), dim3(64), 0, ctx->stream, gz, out, d_jobs, nd, d_len, d_st);
+        hipLaunchKernelGGL(vk_inflate_kernel, dim3(nd), dim3(64), 0, ctx->stream, gz, out, d_jobs, nd, d_len, d_st, d_nm, d_cr);
         VK_HIP(ctx, hipGetLastError());
         std::vector<unsigned long long> h_len(nd);
-        std::vector<uint32_t> h_st(nd);
+        std::vector<uint32_t> h_st(3 * static_cast<size_t>(nd));
         VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, len_b, hipMemcpyDeviceToHost, ctx->stream));
-        VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, st_b, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, 3 * st_b, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also keeps `jobs` alive until the copy has read it)
         for (uint32_t j = 0; j < nd; ++j) {
-            out_lengths[direct[j]] = h_len[j];
-            status[direct[j]] = h_st[j];
+            const uint32_t i = direct[j];
+            out_lengths[i] = h_len[j];
+            status[i] = h_st[j];
+            if (h_st[j] == 0 && h_st[nd + j] == 1)
+                crc_jobs.push_back(GzCrcJob{out_offsets[i], h_len[j], 0, 0}), crc_file.push_back(i), crc_want.push_back(h_st[2 * nd + j]);
         }
+    }
+    // the check word of every single-member file against the CRC-32 of the text it inflated to
+    if (!crc_jobs.empty()) {
+        std::vector<uint32_t> got;
+        int rc = gz_text_crc(ctx, out, crc_jobs, got);
+        if (rc) return rc;
+        for (size_t j = 0; j < crc_jobs.size(); ++j)
+            if (got[j] != crc_want[j]) status[crc_file[j]] |= VK_GZ_BAD_CRC;
     }
     return VK_OK;
 }

@@ -194,7 +194,7 @@ class ImageEngine:
         """Device half: one H2D DMA of the plain text, one of the compressed files, and the gzip files
         inflated in HBM into their text slots (vk_inflate_device).  Returns (tensor, offsets, lengths);
         the staging buffer may be refilled once this returns.  A gzip file the GPU rejects (bad header
-        or data, truncated, size word wrong) gets length 0 and a line on stderr."""
+        or data, truncated, size word or CRC-32 wrong) gets length 0 and a line on stderr."""
         torch = _torch()
         pinned, plain_total, stage_total = staged["pinned"], staged["plain_total"], staged["stage_total"]
         offs, lens, is_gz = staged["offs"], staged["lens"].copy(), staged["is_gz"]

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: what the chunk decoder's wavefronts spend their time on, and how evenly the chunks finish
+(stamped build: hipcc ... -DVK_GZ_STAMPS -o tools/libvk_gzstamps.so).  Shares only -- the stamped build's run
+time means nothing.  python tools/gz_stamps.py [nfiles] [reads] [level]"""
+import ctypes as C
+import os
+import sys
+import zlib
+
+os.environ["VKIMG_LIB"] = "tools/libvk_gzstamps.so"
+sys.path.insert(0, ".")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from varkoder_amd import synth  # noqa: E402
+from varkoder_amd.engine import ImageEngine  # noqa: E402
+
+nfiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reads = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+eng = ImageEngine(k=7, mapping="cgr")
+texts = [synth.sample_fastq(i, reads, 150, dist=i & 1).tobytes() for i in range(min(nfiles, 8))]
+comp = []
+for t in texts:
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    comp.append(co.compress(t) + co.flush())
+files = [comp[i % len(comp)] for i in range(nfiles)]
+tl = [len(texts[i % len(texts)]) for i in range(nfiles)]
+offs, pos = [], 0
+for f in files:
+    offs.append(pos)
+    pos += (len(f) + 15) // 16 * 16
+host = np.zeros(pos + 16, dtype=np.uint8)
+for o, f in zip(offs, files):
+    host[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
+dev = torch.from_numpy(host).cuda()
+ooffs, pos = [], 0
+for n in tl:
+    ooffs.append(pos)
+    pos += (n + 15) // 16 * 16
+out = torch.empty(pos + 16, dtype=torch.uint8, device="cuda")
+args = (dev, np.array(offs, dtype=np.uint64), np.array([len(f) for f in files], dtype=np.uint64), out,
+        np.array(ooffs, dtype=np.uint64), np.array(tl, dtype=np.uint64))
+for _ in range(2):
+    lens, status = eng.inflate(*args)
+assert not status.any()
+nch = sum((len(f) + (1 << 18) - 1) >> 18 for f in files)
+buf = (C.c_ulonglong * (8 * nch))()
+assert eng.L.vk_debug_read_gz_stamps(buf, nch) == 0
+v = np.frombuffer(buf, dtype=np.uint64).reshape(nch, 8).astype(np.float64)
+v = v[v[:, 1] > 0]
+t0 = v[:, 0].min()
+dur = (v[:, 1] - v[:, 0]) / 100.0            # wall clock ticks of 10 ns -> microseconds
+end = (v[:, 1] - t0) / 100.0
+print(f"{len(v)} chunk wavefronts; kernel span {end.max() / 1e3:.1f} ms")
+for name, x in (("lifetime of a wavefront (ms)", dur / 1e3), ("finishes at (ms)", end / 1e3), ("steps", v[:, 2]), ("tokens", v[:, 3]),
+                ("tokens per step", v[:, 3] / np.maximum(v[:, 2], 1))):
+    q = np.percentile(x, [0, 10, 50, 90, 99, 100])
+    print(f"{name:32s} min {q[0]:10.1f}  p10 {q[1]:10.1f}  median {q[2]:10.1f}  p90 {q[3]:10.1f}  p99 {q[4]:10.1f}  max {q[5]:10.1f}  mean {x.mean():10.1f}")
+tot = v[:, 4:8].sum()
+for name, col in (("peek + lookups", 4), ("chain walk + ring", 5), ("resolve", 6), ("headers + tables", 7)):
+    print(f"{name:20s} {100 * v[:, col].sum() / tot:5.1f} %   {v[:, col].sum() / max(v[:, 2].sum(), 1):9.1f} cycles per step")

@@ -27,7 +27,7 @@
 namespace {
 
 constexpr int kLitRoot = 11, kDistRoot = 9;
-constexpr uint32_t kRing = 256;          // token ring (resolved when fewer than 64 slots are free)
+constexpr uint32_t kRing = 256;          // token ring (resolved when fewer than 65 slots are free)
 constexpr uint32_t kLongMatch = 24;      // matches at least this long are copied by the whole wave
 
 // Table entry (16 bits: the tables are what limits the wavefronts a CU can hold, and a lone wavefront
@@ -37,6 +37,7 @@ constexpr uint32_t kLongMatch = 24;      // matches at least this long are copie
 //   bits 6-15 literal byte, or the index of the length (0..28) / distance (0..29) symbol, whose
 //   base value and extra bits follow from the index by arithmetic (gz_len_of / gz_dist_of).
 constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindBad = 3;
+constexpr uint32_t kKindLong = 4;  // (in registers only) a code longer than a table's root: that token is decoded on the side
 constexpr uint32_t kBadEntry = kKindBad << 4;
 
 struct GzLds {
@@ -190,6 +191,50 @@ __device__ __forceinline__ uint32_t gz_slow(uint64_t w, const uint16_t* cnt, con
     return 0xFFFFu;
 }
 
+// One token decoded the slow way (any code length), for the rare token with a code longer than a table's
+// root: kept out of line so that the token loop stays small.  Every lane computes the same.  Returns
+// tok | used << 32 | kind << 40 (tok as in the ring).
+__device__ __attribute__((noinline)) uint64_t gz_slow_token(const uint16_t* lit, const uint16_t* dst, const uint16_t* lit_cnt,
+                                                           const uint16_t* lit_sym, const uint16_t* dst_cnt,
+                                                           const uint16_t* dst_sym, uint64_t ww) {
+    uint32_t e = lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
+    uint32_t used = e & 15u;
+    if (used == 15u) {
+        uint32_t l;
+        const uint32_t s = gz_slow(ww, lit_cnt, lit_sym, l);
+        used = l;
+        e = gz_lit_entry(s);
+    }
+    uint32_t kind = (e >> 4) & 3u;
+    uint32_t tok = e >> 6;  // literal byte
+    if (kind == kKindLen) {
+        uint32_t lbase, xb;
+        gz_len_of(e >> 6, lbase, xb);
+        const uint32_t len = lbase + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
+        used += xb;
+        const uint64_t w2 = ww >> used;
+        uint32_t d = dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
+        uint32_t dl = d & 15u;
+        if (dl == 15u) {
+            uint32_t l;
+            const uint32_t s = gz_slow(w2, dst_cnt, dst_sym, l);
+            dl = l;
+            d = gz_dist_entry(s);
+        }
+        if (((d >> 4) & 3u) != kKindLen || dl == 0u) {
+            kind = kKindBad;
+        } else {
+            uint32_t dbase, dxb;
+            gz_dist_of(d >> 6, dbase, dxb);
+            const uint32_t dist = dbase + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
+            used += dl + dxb;
+            tok = 0x80000000u | (dist << 9) | len;
+        }
+    }
+    if (used == 0u) kind = kKindBad;
+    return static_cast<uint64_t>(tok) | (static_cast<uint64_t>(used) << 32) | (static_cast<uint64_t>(kind) << 40);
+}
+
 // The header of a dynamic-codes block at bit `pos` (just behind the three block-type bits): HLIT, HDIST,
 // HCLEN, the code-length code, and the run-length coded code lengths, which go to L.lens (literal/length
 // codes at 0.., distance codes at 288..).  Advances pos; false if the header is not valid.
@@ -312,6 +357,263 @@ struct GzChunk {
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
 constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
 
+// ---- the two hot pieces of the decoder, out of line -------------------------------------------------
+// gz_wave below keeps the state of a whole gzip file (a dozen 64-bit uniform values and as many flags);
+// inlined into it, the token loop and the resolver ran out of scalar and vector registers and spilled in
+// their innermost loops.  As functions of their own they get a register allocation of their own; what is
+// uniform comes back to scalar registers through readfirstlane on the way in and out.
+typedef __attribute__((address_space(3))) GzLds* GzLdsP;
+typedef const __attribute__((address_space(1))) uint32_t* GzGlobalU32;
+
+__device__ __forceinline__ uint32_t gz_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t gz_uni64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ int gz_lane() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
+
+__device__ __attribute__((noinline)) uint64_t gz_peek_tail(const uint8_t* in, uint64_t nbytes, uint64_t p) { return gz_peek(in, nbytes, p); }
+
+struct GzRun {
+    uint64_t pos;     // bit position behind the last token taken
+    uint32_t nring;   // tokens in the ring
+    uint32_t code;    // why it stopped
+};
+constexpr uint32_t kRunRing = 0, kRunEob = 1, kRunBad = 2, kRunTrunc = 3;
+
+// Tokens of one DEFLATE block from bit `pos` on, appended to the ring: until the end-of-block code, or
+// until the ring has fewer than 65 free slots.  A step: every lane decodes the token that WOULD start at
+// pos + lane (both tables, straight-line), then the true chain through the 64 answers is walked with one
+// readlane per token.  The compressed stream is held in a register window -- lane j has dword j of 256
+// bytes, read with one coalesced load every ~25 steps -- and a lane picks its 64 bits out of it with three
+// bpermutes; within 512 bytes of the end of the input the bounds-checked peek is used instead.
+__device__ __attribute__((noinline)) GzRun gz_tokens(GzLdsP L, const uint8_t* in_, uint64_t nbytes_, uint64_t pos_, uint32_t nring_) {
+    const int lane = gz_lane();
+    const uint64_t in_addr = gz_uni64(reinterpret_cast<uint64_t>(in_));
+    const uint8_t* in = reinterpret_cast<const uint8_t*>(in_addr);
+    const uint64_t nbytes = gz_uni64(nbytes_), nbits = nbytes * 8;
+    uint64_t pos = gz_uni64(pos_);
+    uint32_t nring = gz_uni(nring_);
+    uint32_t code = kRunRing;
+    long long wpos = 0;      // stream bit position of bit 0 of the window (can be up to 31 below 0)
+    bool have = false;
+    uint32_t win = 0;
+    for (;;) {
+        if (pos >= nbits) { code = kRunTrunc; break; }
+        if (nring + 65 > kRing) { code = kRunRing; break; }
+        uint64_t ww;
+        const uint64_t b0 = pos >> 3;
+        if (b0 + 512 <= nbytes) {
+            if (!have || static_cast<long long>(pos) - wpos > 1800) {
+                const uint64_t al = (in_addr + b0) & ~3ull;
+                win = reinterpret_cast<GzGlobalU32>(al)[lane];
+                wpos = static_cast<long long>(al - in_addr) * 8;
+                have = true;
+            }
+            const uint32_t o = static_cast<uint32_t>(static_cast<long long>(pos) - wpos) + static_cast<uint32_t>(lane);
+            const int q4 = static_cast<int>((o >> 5) << 2);
+            const uint32_t sh = o & 31u;
+            const uint32_t d0 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4, static_cast<int>(win)));
+            const uint32_t d1 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4 + 4, static_cast<int>(win)));
+            const uint32_t d2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4 + 8, static_cast<int>(win)));
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            ww = (static_cast<uint64_t>(hi) << 32) | lo;
+        } else {
+            ww = gz_peek_tail(in, nbytes, pos + lane);
+        }
+        const uint32_t e = L->lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
+        const uint32_t lused = e & 15u;
+        const uint32_t lkind = (e >> 4) & 3u;
+        uint32_t lbase, xb;
+        gz_len_of((e >> 6) & 31u, lbase, xb);
+        const uint32_t len = lbase + (static_cast<uint32_t>(ww >> lused) & ((1u << xb) - 1u));
+        const uint64_t w2 = ww >> (lused + xb);
+        const uint32_t d = L->dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
+        const uint32_t dl = d & 15u;
+        uint32_t dbase, dxb;
+        gz_dist_of((d >> 6) & 31u, dbase, dxb);
+        const uint32_t dist = dbase + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
+        const bool is_len = lkind == kKindLen;
+        const bool longc = lused == 15u || (is_len && dl == 15u);
+        const bool dbad = is_len && (((d >> 4) & 3u) != kKindLen || dl == 0u);
+        const uint32_t used = is_len ? lused + xb + dl + dxb : lused;
+        const uint32_t tok = is_len ? (0x80000000u | (dist << 9) | len) : (e >> 6);
+        const uint32_t kind = longc ? kKindLong : ((dbad || used == 0u) ? kKindBad : lkind);
+        const uint32_t packed = used | (kind << 8);
+        // the true chain through the 64 answers
+        unsigned long long chain = 0;
+        uint32_t at = 0, halt = 0;
+        while (at < 64) {
+            const uint32_t pk = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(packed), at));
+            if (pk >= (kKindEob << 8)) {
+                halt = pk;
+                break;
+            }
+            chain |= 1ull << at;
+            at += pk & 0xFFu;
+        }
+        if ((halt >> 8) == kKindBad) { code = kRunBad; break; }
+        if ((chain >> lane) & 1ull) L->ring[nring + __popcll(chain & ((1ull << lane) - 1ull))] = tok;
+        nring += static_cast<uint32_t>(__popcll(chain));
+        pos += at;
+        if ((halt >> 8) == kKindEob) {
+            pos += halt & 0xFFu;
+            code = pos > nbits ? kRunTrunc : kRunEob;
+            break;
+        }
+        if ((halt >> 8) == kKindLong) {  // the token at `pos` has a code longer than a table's root
+            const uint64_t r = gz_slow_token((const uint16_t*)(L->lit), (const uint16_t*)(L->dst),
+                                             (const uint16_t*)(L->lit_cnt), (const uint16_t*)(L->lit_sym),
+                                             (const uint16_t*)(L->dst_cnt), (const uint16_t*)(L->dst_sym),
+                                             gz_peek_tail(in, nbytes, pos));
+            const uint32_t k2 = gz_uni(static_cast<uint32_t>(r >> 40) & 7u);
+            if (k2 == kKindBad) { code = kRunBad; break; }
+            pos += gz_uni(static_cast<uint32_t>(r >> 32) & 0xFFu);
+            if (k2 == kKindEob) {
+                code = pos > nbits ? kRunTrunc : kRunEob;
+                break;
+            }
+            if (lane == 0) L->ring[nring] = static_cast<uint32_t>(r);
+            ++nring;
+        }
+        if (pos > nbits) { code = kRunTrunc; break; }  // the chain ran off the end of the file
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    GzRun out;
+    out.pos = pos;
+    out.nring = nring;
+    out.code = code;
+    return out;
+}
+
+struct GzRes {
+    uint64_t opos;    // text elements written
+    uint32_t st;      // status bits
+    uint32_t rounds;  // (diagnostics) rounds it took
+};
+
+// The ring's tokens -> text.  Output offsets by prefix sum; then rounds: the longest run of tokens
+// whose sources are already written goes out in parallel, the stores are awaited, and so on.
+// SYM = false: text bytes; SYM = true: u16 elements, positions before the chunk stand for the unknown window.
+template <bool SYM>
+__device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint64_t cap_, uint64_t opos_, uint32_t nring_,
+                                                       uint32_t window_open_, uint64_t member_text0_) {
+    const int lane = gz_lane();
+    typedef __attribute__((address_space(1))) uint8_t* G8;
+    typedef __attribute__((address_space(1))) uint16_t* G16;
+    const uint64_t out_addr = gz_uni64(reinterpret_cast<uint64_t>(out_));
+    G8 out8 = reinterpret_cast<G8>(out_addr);
+    G16 out16 = reinterpret_cast<G16>(out_addr);
+    const uint64_t cap = gz_uni64(cap_), member_text0 = gz_uni64(member_text0_);
+    const uint32_t nring = gz_uni(nring_);
+    const bool window_open = gz_uni(window_open_) != 0u;
+    uint32_t st = 0, rounds = 0;
+    auto load_elem = [&](long long p) -> uint32_t {  // element at output position p (p < 0: the unknown window)
+        if (SYM) {
+            if (p < 0) return 0x8000u | static_cast<uint32_t>(p + 32768);
+            return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto store_elem = [&](uint64_t p, uint32_t v) {
+        if (SYM) out16[p] = static_cast<uint16_t>(v);
+        else out8[p] = static_cast<uint8_t>(v);
+    };
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the ring was written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    uint64_t base = gz_uni64(opos_);   // output offset of ring[t0]
+    for (uint32_t t0 = 0; t0 < nring && st == 0; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t tok = t < nring ? L->ring[t] : 0u;
+        const bool live = t < nring;
+        const bool is_match = (tok >> 31) != 0u;
+        const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
+        const uint32_t dist = (tok >> 9) & 0xFFFFu;
+        // inclusive prefix sum of len over the wave
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        const uint64_t off = base + (incl - len);  // where this lane's token starts
+        if (base + total > cap) { st |= kGzOverflow; break; }
+        // a distance beyond the start of the gzip member is an error
+        const uint64_t reach = window_open ? off + 32768u : off - member_text0;
+        const bool bad = live && is_match && (dist == 0u || dist > reach || dist > 32768u);
+        if (__any(bad)) { st |= kGzBadData; break; }
+        // source ends (exclusive) and rounds
+        const long long src0 = static_cast<long long>(off) - static_cast<long long>(dist);
+        const long long src_end = is_match ? src0 + static_cast<long long>(len < dist ? len : dist) : 0;
+        long long frontier = static_cast<long long>(base);  // everything below is written and visible
+        uint32_t done = 0;                                  // tokens [0, done) of this group are out
+        const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
+        while (done < ngroup) {
+            const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
+                               (!is_match || src_end <= frontier);
+            const unsigned long long rb = __ballot(ready);
+            // first lane >= done that is not ready
+            const unsigned long long notready = ~rb & (~0ull << done);
+            uint32_t upto = notready ? static_cast<uint32_t>(__builtin_ctzll(notready)) : 64u;
+            if (upto > ngroup) upto = ngroup;
+            const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
+            // short tokens: one lane each
+            if (mine && !is_match) {
+                store_elem(off, tok & 0xFFu);
+            } else if (mine && len < kLongMatch) {
+                // (every source lies below the frontier: the loads do not depend on this round's stores, four in flight)
+                uint32_t idx = 0;  // i mod dist
+                for (uint32_t i = 0; i < len; i += 4) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[u] = i + u < len ? load_elem(src0 + idx) : 0u;
+                        idx = idx + 1u == dist ? 0u : idx + 1u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i + u < len) store_elem(off + i + u, v[u]);
+                }
+            }
+            // long matches: the whole wave, one after the other (sources below the frontier: independent)
+            unsigned long long lb = __ballot(mine && is_match && len >= kLongMatch);
+            while (lb) {
+                const int l = __builtin_ctzll(lb);
+                lb &= lb - 1;
+                const uint32_t mlen = __shfl(len, l), mdist = __shfl(dist, l);
+                const uint32_t lo = __shfl(static_cast<uint32_t>(off), l), hi = __shfl(static_cast<uint32_t>(off >> 32), l);
+                const uint64_t moff = (static_cast<uint64_t>(hi) << 32) | lo;
+                const long long msrc = static_cast<long long>(moff) - static_cast<long long>(mdist);
+                for (uint32_t i = lane; i < mlen; i += 64) store_elem(moff + i, load_elem(msrc + (i < mdist ? i : i % mdist)));
+            }
+            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
+            done = upto;
+            // start of the first token still to do
+            frontier = static_cast<long long>(upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total);
+        }
+        base += total;
+    }
+    GzRes r;
+    r.opos = base;
+    r.st = st;
+    r.rounds = rounds;
+    return r;
+}
+
+#ifdef VK_GZ_STAMPS
+// Diagnostic build only (tools/gz_stamps.py): per-chunk clocks of the chunk decoder, in a debug buffer that
+// nothing else reads.  [c][0..1] wall clock at start / end, [2] resolve rounds, [3] tokens, [4..7] cycles in:
+// gz_tokens, -, gz_resolve, block headers and table builds.
+__device__ unsigned long long g_gz_stamps[16384][8];
+#define GZ_T(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GZ_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define GZ_T(x) do { } while (0)
+#define GZ_ADD(acc, a, b) do { } while (0)
+#endif
+
 // The decoder of one wavefront.  SYM = false: a whole file, text bytes straight to `out8`.
 // SYM = true: one chunk of a file whose preceding 32 KiB of text are not known yet: u16 elements to
 // `out16`, a value below 256 is a text byte, 0x8000 | w stands for byte w of that unknown window
@@ -324,6 +626,10 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                         uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc) {
     const int lane = threadIdx.x & 63;
     const uint64_t nbits = nbytes * 8;
+#ifdef VK_GZ_STAMPS
+    unsigned long long ta = 0, tb = 0, tc = 0, acc_tok = 0, acc_res = 0, acc_hdr = 0, n_rounds = 0, n_tok = 0;
+    const unsigned long long wall0 = wall_clock64();
+#endif
     uint64_t pos = start_bit;   // bit position in the input (wave-uniform, like everything that steers the loops)
     uint64_t opos = 0;          // text bytes (elements) written
     uint32_t st = 0;
@@ -349,74 +655,23 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
         else out8[p] = static_cast<uint8_t>(v);
     };
 
-    // The ring's tokens -> text.  Output offsets by prefix sum; then rounds: the longest run of tokens
-    // whose sources are already written goes out in parallel, the stores are awaited, and so on.
+    // The ring's tokens -> text (gz_resolve, out of line: one copy of it, with registers of its own).
     auto resolve = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the ring was written by other lanes of this wave
-        __builtin_amdgcn_wave_barrier();
-        uint64_t base = opos;   // output offset of ring[t0]
-        for (uint32_t t0 = 0; t0 < nring && st == 0; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            const uint32_t tok = t < nring ? L.ring[t] : 0u;
-            const bool live = t < nring;
-            const bool is_match = (tok >> 31) != 0u;
-            const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
-            const uint32_t dist = (tok >> 9) & 0xFFFFu;
-            // inclusive prefix sum of len over the wave
-            uint32_t incl = len;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            const uint64_t off = base + (incl - len);  // where this lane's token starts
-            if (base + total > cap) { st |= kGzOverflow; break; }
-            // a distance beyond the start of the gzip member is an error
-            const uint64_t reach = window_open ? off + 32768u : off - member_text0;
-            const bool bad = live && is_match && (dist == 0u || dist > reach || dist > 32768u);
-            if (__any(bad)) { st |= kGzBadData; break; }
-            // source ends (exclusive) and rounds
-            const long long src0 = static_cast<long long>(off) - static_cast<long long>(dist);
-            const long long src_end = is_match ? src0 + static_cast<long long>(len < dist ? len : dist) : 0;
-            long long frontier = static_cast<long long>(base);  // everything below is written and visible
-            uint32_t done = 0;                                  // tokens [0, done) of this group are out
-            const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
-            while (done < ngroup) {
-                const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
-                                   (!is_match || src_end <= frontier);
-                const unsigned long long rb = __ballot(ready);
-                // first lane >= done that is not ready
-                const unsigned long long notready = ~rb & (~0ull << done);
-                uint32_t upto = notready ? static_cast<uint32_t>(__builtin_ctzll(notready)) : 64u;
-                if (upto > ngroup) upto = ngroup;
-                const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
-                // short tokens: one lane each
-                if (mine && !is_match) {
-                    store_elem(off, tok & 0xFFu);
-                } else if (mine && len < kLongMatch) {
-                    for (uint32_t i = 0; i < len; ++i) store_elem(off + i, load_elem(src0 + (i < dist ? i : i % dist)));
-                }
-                // long matches: the whole wave, one after the other (sources below the frontier: independent)
-                unsigned long long lb = __ballot(mine && is_match && len >= kLongMatch);
-                while (lb) {
-                    const int l = __builtin_ctzll(lb);
-                    lb &= lb - 1;
-                    const uint32_t mlen = __shfl(len, l), mdist = __shfl(dist, l);
-                    const uint32_t lo = __shfl(static_cast<uint32_t>(off), l), hi = __shfl(static_cast<uint32_t>(off >> 32), l);
-                    const uint64_t moff = (static_cast<uint64_t>(hi) << 32) | lo;
-                    const long long msrc = static_cast<long long>(moff) - static_cast<long long>(mdist);
-                    for (uint32_t i = lane; i < mlen; i += 64) store_elem(moff + i, load_elem(msrc + (i < mdist ? i : i % mdist)));
-                }
-                __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
-                done = upto;
-                // start of the first token still to do
-                frontier = static_cast<long long>(upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total);
-            }
-            base += total;
-        }
-        opos = base;
+#ifdef VK_GZ_STAMPS
+        unsigned long long r0, r1;
+        GZ_T(r0);
+        n_tok += nring;
+#endif
+        const GzRes r = gz_resolve<SYM>((GzLdsP)(&L), SYM ? static_cast<void*>(out16) : static_cast<void*>(out8),
+                                        cap, opos, nring, window_open ? 1u : 0u, member_text0);
+        opos = gz_uni64(r.opos);
+        st |= gz_uni(r.st);
         nring = 0;
+#ifdef VK_GZ_STAMPS
+        GZ_T(r1);
+        acc_res += r1 - r0;
+        n_rounds += gz_uni(r.rounds);
+#endif
     };
 
     // ---- gzip members ---------------------------------------------------------------------------
@@ -460,6 +715,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
         bool last = false;
         while (!last && st == 0) {
             if (pos + 3 > nbits) { st |= kGzTruncated; break; }
+            GZ_T(ta);
             uint64_t w = gz_peek(in, nbytes, pos);
             last = (w & 1u) != 0u;
             const uint32_t type = static_cast<uint32_t>(w >> 1) & 3u;
@@ -504,74 +760,21 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                     break;
                 }
 
-                // ---- tokens -----------------------------------------------------------------
+                GZ_T(tb);
+                GZ_ADD(acc_hdr, ta, tb);
+                // ---- tokens (gz_tokens: until the end of the block, or until the ring is nearly full) ----
                 bool eob = false;
                 while (!eob && st == 0) {
-                    if (pos >= nbits) { st |= kGzTruncated; break; }
-                    if (nring + 64 > kRing) {
-                        resolve();
-                        if (st) break;
-                    }
-                    // every lane: the token that would start at pos + lane
-                    const uint64_t ww = gz_peek(in, nbytes, pos + lane);
-                    uint32_t e = L.lit[static_cast<uint32_t>(ww) & ((1u << kLitRoot) - 1u)];
-                    uint32_t used = e & 15u;
-                    if (used == 15u) {  // a long code (rare)
-                        uint32_t l;
-                        const uint32_t s = gz_slow(ww, L.lit_cnt, L.lit_sym, l);
-                        used = l;
-                        e = gz_lit_entry(s);
-                    }
-                    uint32_t kind = (e >> 4) & 3u;
-                    uint32_t tok = e >> 6;  // literal byte
-                    if (kind == kKindLen) {
-                        uint32_t lbase, xb;
-                        gz_len_of(e >> 6, lbase, xb);
-                        const uint32_t len = lbase + (static_cast<uint32_t>(ww >> used) & ((1u << xb) - 1u));
-                        used += xb;
-                        const uint64_t w2 = ww >> used;
-                        uint32_t d = L.dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
-                        uint32_t dl = d & 15u;
-                        if (dl == 15u) {
-                            uint32_t l;
-                            const uint32_t s = gz_slow(w2, L.dst_cnt, L.dst_sym, l);
-                            dl = l;
-                            d = gz_dist_entry(s);
-                        }
-                        if (((d >> 4) & 3u) != kKindLen || dl == 0u) {
-                            kind = kKindBad;
-                        } else {
-                            uint32_t dbase, dxb;
-                            gz_dist_of(d >> 6, dbase, dxb);
-                            const uint32_t dist = dbase + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
-                            used += dl + dxb;
-                            tok = 0x80000000u | (dist << 9) | len;
-                        }
-                    }
-                    if (used == 0u) kind = kKindBad;
-                    // the true chain through the 64 answers
-                    unsigned long long chain = 0;
-                    uint32_t at = 0, ntok = 0;
-                    bool bad = false;
-                    while (at < 64) {
-                        const uint32_t k = __builtin_amdgcn_readlane(static_cast<int>(kind), at);
-                        if (k == kKindBad) { bad = true; break; }
-                        const uint32_t u = __builtin_amdgcn_readlane(static_cast<int>(used), at);
-                        if (k == kKindEob) {
-                            eob = true;
-                            at += u;
-                            break;
-                        }
-                        chain |= 1ull << at;
-                        ++ntok;
-                        at += u;
-                    }
-                    if (bad) { st |= kGzBadData; break; }
-                    if ((chain >> lane) & 1ull)
-                        L.ring[nring + __popcll(chain & ((1ull << lane) - 1ull))] = tok;
-                    nring += ntok;
-                    pos += at;
-                    if (pos > nbits) st |= kGzTruncated;  // the chain ran off the end of the file
+                    GZ_T(tb);
+                    const GzRun r = gz_tokens((GzLdsP)(&L), in, nbytes, pos, nring);
+                    pos = gz_uni64(r.pos);
+                    nring = gz_uni(r.nring);
+                    const uint32_t code = gz_uni(r.code);
+                    GZ_T(tc);
+                    GZ_ADD(acc_tok, tb, tc);
+                    if (code == kRunRing) resolve();
+                    else if (code == kRunEob) eob = true;
+                    else st |= code == kRunBad ? kGzBadData : kGzTruncated;
                 }
                 if (st) break;
             }
@@ -605,6 +808,13 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
         }
     }
     if (st == 0 && stop) resolve();
+#ifdef VK_GZ_STAMPS
+    if (SYM && lane == 0 && blockIdx.x < 16384) {
+        unsigned long long* g = g_gz_stamps[blockIdx.x];
+        g[0] = wall0; g[1] = wall_clock64(); g[2] = n_rounds; g[3] = n_tok;
+        g[4] = acc_tok; g[5] = 0; g[6] = acc_res; g[7] = acc_hdr;
+    }
+#endif
     out_len = opos;
     out_status = st;
     out_next = next;

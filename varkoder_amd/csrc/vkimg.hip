@@ -804,6 +804,12 @@ int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t np
     return VK_OK;
 }
 
+#ifdef VK_GZ_STAMPS
+int vk_debug_read_gz_stamps(unsigned long long* out, uint32_t nchunks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gz_stamps), static_cast<size_t>(nchunks) * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 #ifdef VK_STAMPS
 int vk_debug_read_stamps(unsigned long long* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_vk_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;

@@ -40,8 +40,9 @@ for n in tl:
 out = torch.empty(pos + 16, dtype=torch.uint8, device="cuda")
 args = (dev, np.array(offs, dtype=np.uint64), np.array([len(f) for f in files], dtype=np.uint64), out,
         np.array(ooffs, dtype=np.uint64), np.array(tl, dtype=np.uint64))
-for _ in range(2):
-    lens, status = eng.inflate(*args)
+lens, status = eng.inflate(*args)
+assert eng.L.vk_debug_read_gz_res(None, 0, 1) == 0
+lens, status = eng.inflate(*args)
 assert not status.any()
 nch = sum((len(f) + (1 << 18) - 1) >> 18 for f in files)
 buf = (C.c_ulonglong * (8 * nch))()
@@ -52,10 +53,18 @@ t0 = v[:, 0].min()
 dur = (v[:, 1] - v[:, 0]) / 100.0            # wall clock ticks of 10 ns -> microseconds
 end = (v[:, 1] - t0) / 100.0
 print(f"{len(v)} chunk wavefronts; kernel span {end.max() / 1e3:.1f} ms")
-for name, x in (("lifetime of a wavefront (ms)", dur / 1e3), ("finishes at (ms)", end / 1e3), ("steps", v[:, 2]), ("tokens", v[:, 3]),
-                ("tokens per step", v[:, 3] / np.maximum(v[:, 2], 1))):
+for name, x in (("lifetime of a wavefront (ms)", dur / 1e3), ("finishes at (ms)", end / 1e3), ("resolve rounds", v[:, 2]), ("tokens", v[:, 3]),
+                ("tokens per round", v[:, 3] / np.maximum(v[:, 2], 1))):
     q = np.percentile(x, [0, 10, 50, 90, 99, 100])
     print(f"{name:32s} min {q[0]:10.1f}  p10 {q[1]:10.1f}  median {q[2]:10.1f}  p90 {q[3]:10.1f}  p99 {q[4]:10.1f}  max {q[5]:10.1f}  mean {x.mean():10.1f}")
 tot = v[:, 4:8].sum()
-for name, col in (("peek + lookups", 4), ("chain walk + ring", 5), ("resolve", 6), ("headers + tables", 7)):
-    print(f"{name:20s} {100 * v[:, col].sum() / tot:5.1f} %   {v[:, col].sum() / max(v[:, 2].sum(), 1):9.1f} cycles per step")
+for name, col in (("gz_tokens", 4), ("gz_resolve", 6), ("headers + tables", 7)):
+    print(f"{name:20s} {100 * v[:, col].sum() / tot:5.1f} %   {v[:, col].sum() / max(v[:, 3].sum(), 1):9.1f} cycles per token")
+buf2 = (C.c_ulonglong * (4 * nch))()
+assert eng.L.vk_debug_read_gz_res(buf2, nch, 0) == 0
+r = np.frombuffer(buf2, dtype=np.uint64).reshape(nch, 4).astype(np.float64)
+rt = r.sum()
+rounds = max(v[:, 2].sum(), 1)
+print("inside gz_resolve (the direct path's blocks, if any, are counted in too):")
+for name, col in (("group set-up (ring, prefix sum, checks)", 0), ("round head + masks", 1), ("element loop (loads, stores issued)", 2), ("store drain", 3)):
+    print(f"  {name:42s} {100 * r[:, col].sum() / rt:5.1f} %   {r[:, col].sum() / rounds:9.1f} cycles per round")

@@ -28,7 +28,6 @@ namespace {
 
 constexpr int kLitRoot = 11, kDistRoot = 9;
 constexpr uint32_t kRing = 256;          // token ring (resolved when fewer than 65 slots are free)
-constexpr uint32_t kLongMatch = 24;      // matches at least this long are copied by the whole wave
 
 // Table entry (16 bits: the tables are what limits the wavefronts a CU can hold, and a lone wavefront
 // issues an instruction every ~4 ns -- throughput comes from many of them):
@@ -47,8 +46,14 @@ struct GzLds {
     uint16_t lit_sym[288];       // symbols ordered by (code length, symbol): canonical decoding of long codes
     uint16_t dst_sym[32];
     uint16_t lit_cnt[16], dst_cnt[16];
-    uint8_t lens[320];           // code lengths of the block being set up
-    uint8_t pre[128];            // code-length code: 7-bit lookup, sym | len << 5
+    union {
+        uint8_t lens[320];       // block set-up: code lengths
+        uint32_t start[64];      // resolver: output offsets of the 64 tokens in hand
+    };
+    union {
+        uint8_t pre[128];                // block set-up: code-length code, 7-bit lookup, sym | len << 5
+        unsigned long long mask[16];     // resolver: which elements of 16 x 64 output positions begin a token
+    };
 };
 
 // length symbol 257 + i: base length and extra bits (RFC 1951 3.2.5), i = 0..28
@@ -357,6 +362,19 @@ struct GzChunk {
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
 constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
 
+#ifdef VK_GZ_STAMPS
+// Diagnostic build only (tools/gz_stamps.py): per-chunk clocks of the chunk decoder, in a debug buffer that
+// nothing else reads.  [c][0..1] wall clock at start / end, [2] resolve rounds, [3] tokens, [4..7] cycles in:
+// gz_tokens, -, gz_resolve, block headers and table builds.
+__device__ unsigned long long g_gz_stamps[16384][8];
+__device__ unsigned long long g_gz_res[16384][4];   // gz_resolve: group set-up, round head + masks, element loop, store drain
+#define GZ_T(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GZ_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define GZ_T(x) do { } while (0)
+#define GZ_ADD(acc, a, b) do { } while (0)
+#endif
+
 // ---- the two hot pieces of the decoder, out of line -------------------------------------------------
 // gz_wave below keeps the state of a whole gzip file (a dozen 64-bit uniform values and as many flags);
 // inlined into it, the token loop and the resolver ran out of scalar and vector registers and spilled in
@@ -509,12 +527,9 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
     const uint32_t nring = gz_uni(nring_);
     const bool window_open = gz_uni(window_open_) != 0u;
     uint32_t st = 0, rounds = 0;
-    auto load_elem = [&](long long p) -> uint32_t {  // element at output position p (p < 0: the unknown window)
-        if (SYM) {
-            if (p < 0) return 0x8000u | static_cast<uint32_t>(p + 32768);
-            return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto load_raw = [&](long long p) -> uint32_t {  // element at output position p >= 0, written by this wave before
+        if (SYM) return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto store_elem = [&](uint64_t p, uint32_t v) {
         if (SYM) out16[p] = static_cast<uint16_t>(v);
@@ -523,7 +538,11 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the ring was written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
     uint64_t base = gz_uni64(opos_);   // output offset of ring[t0]
+#ifdef VK_GZ_STAMPS
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, qa = 0, qb = 0, qc = 0, qd = 0;
+#endif
     for (uint32_t t0 = 0; t0 < nring && st == 0; t0 += 64) {
+        GZ_T(q0);
         const uint32_t t = t0 + lane;
         const uint32_t tok = t < nring ? L->ring[t] : 0u;
         const bool live = t < nring;
@@ -544,13 +563,22 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
         const uint64_t reach = window_open ? off + 32768u : off - member_text0;
         const bool bad = live && is_match && (dist == 0u || dist > reach || dist > 32768u);
         if (__any(bad)) { st |= kGzBadData; break; }
-        // source ends (exclusive) and rounds
+        // Source ends (exclusive) and rounds.  A round writes the elements of tokens [done, upto) with the whole
+        // wave, lane = output position, 1024 positions at a time: the tokens that begin there set their bits in
+        // sixteen 64-bit masks (one LDS atomic), a position's token is the rank of its bit, and since every
+        // source of a round lies below the frontier the loads are independent of its stores: four in flight.
         const long long src0 = static_cast<long long>(off) - static_cast<long long>(dist);
         const long long src_end = is_match ? src0 + static_cast<long long>(len < dist ? len : dist) : 0;
+        const uint32_t start = incl - len;                  // relative to `base`
+        L->start[lane] = start;
         long long frontier = static_cast<long long>(base);  // everything below is written and visible
         uint32_t done = 0;                                  // tokens [0, done) of this group are out
+        uint32_t r0 = 0;                                    // = start of token `done`
         const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
+        GZ_T(q1);
+        GZ_ADD(qa, q0, q1);
         while (done < ngroup) {
+            GZ_T(q1);
             const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
                                (!is_match || src_end <= frontier);
             const unsigned long long rb = __ballot(ready);
@@ -559,60 +587,90 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
             uint32_t upto = notready ? static_cast<uint32_t>(__builtin_ctzll(notready)) : 64u;
             if (upto > ngroup) upto = ngroup;
             const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
-            // short tokens: one lane each
-            if (mine && !is_match) {
-                store_elem(off, tok & 0xFFu);
-            } else if (mine && len < kLongMatch) {
-                // (every source lies below the frontier: the loads do not depend on this round's stores, four in flight)
-                uint32_t idx = 0;  // i mod dist
-                for (uint32_t i = 0; i < len; i += 4) {
-                    uint32_t v[4];
+            const uint32_t r1 = upto < ngroup ? gz_uni(__shfl(start, static_cast<int>(upto))) : total;
+            for (uint32_t s0 = r0; s0 < r1; s0 += 1024) {
+                if (lane < 16) L->mask[lane] = 0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rel = start - s0;
+                if (mine && start >= s0 && rel < 1024u) __hip_atomic_fetch_or(&L->mask[rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                // tokens of the round that begin before s0 (the first of them owns the positions up to the first bit)
+                uint32_t before = done + static_cast<uint32_t>(__popcll(__ballot(mine && start < s0)));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t nwin = (((r1 - s0 < 1024u ? r1 - s0 : 1024u) + 63u) >> 6);
+                GZ_T(q2);
+                GZ_ADD(qb, q1, q2);
+                for (uint32_t w0 = 0; w0 < nwin; w0 += 4) {
+                    // Four windows at a time, in stages without a branch around any memory operation (the
+                    // compiler waits for a load at the end of the branch it sits in): masks, owners, the
+                    // owners' tokens and offsets, sources, stores.  Positions past the round's end and
+                    // literals load a harmless element (position 0) and are masked out afterwards.
+                    unsigned long long m[4];
+                    uint32_t own[4], tk[4], ts[4], raw[4];
+                    long long src[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) m[u] = L->mask[w0 + u];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        v[u] = i + u < len ? load_elem(src0 + idx) : 0u;
-                        idx = idx + 1u == dist ? 0u : idx + 1u;
+                        const unsigned long long mu = gz_uni64(m[u]);
+                        own[u] = before + static_cast<uint32_t>(__popcll(mu & (~0ull >> (63 - lane)))) - 1u;  // the last token that begins at or before e
+                        before += static_cast<uint32_t>(__popcll(mu));
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i + u < len) store_elem(off + i + u, v[u]);
+                    for (int u = 0; u < 4; ++u) {
+                        tk[u] = L->ring[t0 + own[u]];
+                        ts[u] = L->start[own[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t e = s0 + 64u * (w0 + u) + lane;   // relative to `base`
+                        const uint32_t d = (tk[u] >> 9) & 0xFFFFu;
+                        uint32_t i = e - ts[u];
+                        const bool act = e < r1 && (tk[u] >> 31) != 0u;
+                        if (act && i >= d) i = d == 1u ? 0u : i % d;
+                        src[u] = static_cast<long long>(base + ts[u]) - static_cast<long long>(d) + i;
+                        if (!act) src[u] = 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) raw[u] = load_raw(src[u] < 0 ? 0 : src[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t e = s0 + 64u * (w0 + u) + lane;
+                        uint32_t v = raw[u];
+                        if (SYM && src[u] < 0) v = 0x8000u | static_cast<uint32_t>(src[u] + 32768);  // the unknown window
+                        if ((tk[u] >> 31) == 0u) v = tk[u] & 0xFFu;
+                        if (e < r1) store_elem(base + e, v);
+                    }
                 }
             }
-            // long matches: the whole wave, one after the other (sources below the frontier: independent)
-            unsigned long long lb = __ballot(mine && is_match && len >= kLongMatch);
-            while (lb) {
-                const int l = __builtin_ctzll(lb);
-                lb &= lb - 1;
-                const uint32_t mlen = __shfl(len, l), mdist = __shfl(dist, l);
-                const uint32_t lo = __shfl(static_cast<uint32_t>(off), l), hi = __shfl(static_cast<uint32_t>(off >> 32), l);
-                const uint64_t moff = (static_cast<uint64_t>(hi) << 32) | lo;
-                const long long msrc = static_cast<long long>(moff) - static_cast<long long>(mdist);
-                for (uint32_t i = lane; i < mlen; i += 64) store_elem(moff + i, load_elem(msrc + (i < mdist ? i : i % mdist)));
-            }
+#ifdef VK_GZ_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            q3 = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+            qc += q3 - q2;
+#endif
             __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
+            GZ_T(q1);
+            GZ_ADD(qd, q3, q1);
+            ++rounds;
             done = upto;
-            // start of the first token still to do
-            frontier = static_cast<long long>(upto < ngroup ? base + __shfl(incl - len, static_cast<int>(upto)) : base + total);
+            r0 = r1;
+            frontier = static_cast<long long>(base + r1);
         }
         base += total;
     }
+#ifdef VK_GZ_STAMPS
+    if (lane == 0 && blockIdx.x < 16384) {
+        g_gz_res[blockIdx.x][0] += qa; g_gz_res[blockIdx.x][1] += qb; g_gz_res[blockIdx.x][2] += qc; g_gz_res[blockIdx.x][3] += qd;
+    }
+#endif
     GzRes r;
     r.opos = base;
     r.st = st;
     r.rounds = rounds;
     return r;
 }
-
-#ifdef VK_GZ_STAMPS
-// Diagnostic build only (tools/gz_stamps.py): per-chunk clocks of the chunk decoder, in a debug buffer that
-// nothing else reads.  [c][0..1] wall clock at start / end, [2] resolve rounds, [3] tokens, [4..7] cycles in:
-// gz_tokens, -, gz_resolve, block headers and table builds.
-__device__ unsigned long long g_gz_stamps[16384][8];
-#define GZ_T(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define GZ_ADD(acc, a, b) acc += (b) - (a)
-#else
-#define GZ_T(x) do { } while (0)
-#define GZ_ADD(acc, a, b) do { } while (0)
-#endif
 
 // The decoder of one wavefront.  SYM = false: a whole file, text bytes straight to `out8`.
 // SYM = true: one chunk of a file whose preceding 32 KiB of text are not known yet: u16 elements to
@@ -646,9 +704,9 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     auto load_elem = [&](long long p) -> uint32_t {  // element at output position p (p < 0: the unknown window)
         if (SYM) {
             if (p < 0) return 0x8000u | static_cast<uint32_t>(p + 32768);
-            return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return __hip_atomic_load(out16 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(out8 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto store_elem = [&](uint64_t p, uint32_t v) {
         if (SYM) out16[p] = static_cast<uint16_t>(v);
@@ -850,7 +908,8 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every 256 KiB chunk of
 // the compressed file: a cheap test of every bit offset by 64 lanes (block type, code counts, the
 // code-length code must be complete), then the full header parse and table build of the decoder for
-// the few that pass.  (2) vk_gzchunk_kernel decodes every chunk from its start to the start of a later
+// the few that pass, and for what passes that a decode of the block to its end, which must be followed by
+// another plausible block header.  (2) vk_gzchunk_kernel decodes every chunk from its start to the start of a later
 // chunk, with the unknown window kept symbolic (gz_wave<true>).  A start that was not a real block
 // start is never reached exactly by the chunk before it, which simply decodes on to the next one; the
 // host follows the `next` links from chunk 0.  (3) vk_gzwin_kernel walks the chunks of a file in order
@@ -898,10 +957,47 @@ __global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict
             b &= b - 1;
             uint64_t pos = p0 + l + 3;
             uint32_t nlit, ndist;
-            if (gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
-                gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
-                gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane))
-                found = p0 + l;
+            if (!(gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
+                  gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
+                  gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane)))
+                continue;
+            // Random bits pass all that about once in 10^8 positions, i.e. in one chunk of a hundred, and a false
+            // start costs the chunk before it a second chunk's worth of decoding while every other wavefront
+            // has finished.  So: decode the candidate block to its end (tokens dropped) and ask for a
+            // plausible block header behind it.  A block too long to check (2 chunks) is taken on trust.
+            bool ok = true, at_end = false;
+            const uint64_t limit = pos + 16ull * kGzChunkBytes;
+            for (;;) {
+                const GzRun r = gz_tokens((GzLdsP)(&L), in, nbytes, pos, 0);
+                pos = gz_uni64(r.pos);
+                const uint32_t code = gz_uni(r.code);
+                if (code == kRunEob) {
+                    at_end = true;
+                    break;
+                }
+                if (code != kRunRing) ok = false;
+                if (!ok || pos > limit) break;
+            }
+            if (ok && at_end) {
+                ok = pos + 3 <= nbits;
+                if (ok) {
+                    const uint64_t wn = gz_peek(in, nbytes, pos);
+                    const uint32_t type = static_cast<uint32_t>(wn >> 1) & 3u;
+                    pos += 3;
+                    if (type == 3) {
+                        ok = false;
+                    } else if (type == 0) {
+                        const uint64_t bb = (pos + 7) >> 3;
+                        ok = bb + 4 <= nbytes &&
+                             ((in[bb] | (static_cast<uint32_t>(in[bb + 1]) << 8)) ^ (in[bb + 2] | (static_cast<uint32_t>(in[bb + 3]) << 8))) == 0xFFFFu;
+                    } else if (type == 2) {
+                        ok = gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
+                             gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
+                             gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane);
+                    }
+                }
+            }
+            if (ok) found = p0 + l;
         }
     }
     if (lane == 0) starts[c] = found;

@@ -805,6 +805,13 @@ int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t np
 }
 
 #ifdef VK_GZ_STAMPS
+int vk_debug_read_gz_res(unsigned long long* out, uint32_t nchunks, int clear) {
+    if (clear) {
+        static unsigned long long zeros[16384 * 4];
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_gz_res), zeros, sizeof(zeros)) == hipSuccess ? 0 : 2;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gz_res), static_cast<size_t>(nchunks) * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
 int vk_debug_read_gz_stamps(unsigned long long* out, uint32_t nchunks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gz_stamps), static_cast<size_t>(nchunks) * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }

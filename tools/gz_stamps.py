@@ -68,3 +68,12 @@ rounds = max(v[:, 2].sum(), 1)
 print("inside gz_resolve (the direct path's blocks, if any, are counted in too):")
 for name, col in (("group set-up (ring, prefix sum, checks)", 0), ("round head + masks", 1), ("element loop (loads, stores issued)", 2), ("store drain", 3)):
     print(f"  {name:42s} {100 * r[:, col].sum() / rt:5.1f} %   {r[:, col].sum() / rounds:9.1f} cycles per round")
+buf3 = (C.c_ulonglong * (8 * nch))()
+assert eng.L.vk_debug_read_gz_find(buf3, nch) == 0
+f = np.frombuffer(buf3, dtype=np.uint64).reshape(nch, 8).astype(np.float64)
+f = f[f[:, 0] > 0]
+print("vk_gzfind_kernel, per chunk:")
+for name, x in (("wall time (ms)", f[:, 0] / 1e5), ("full header tests (Mcycles)", f[:, 1] / 1e6), ("verification (Mcycles)", f[:, 2] / 1e6), ("candidates tested in full", f[:, 3]),
+                ("  of them above 30 kcycles", f[:, 4]), ("  their cycles (M)", f[:, 5] / 1e6), ("  the longest test (kcycles)", f[:, 6] / 1e3), ("scan iterations (64 positions)", f[:, 7])):
+    q = np.percentile(x, [0, 50, 90, 99, 100])
+    print(f"  {name:32s} min {q[0]:9.2f}  median {q[1]:9.2f}  p90 {q[2]:9.2f}  p99 {q[3]:9.2f}  max {q[4]:9.2f}  mean {x.mean():9.2f}")

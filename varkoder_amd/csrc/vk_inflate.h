@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int kLitRoot = 11, kDistRoot = 9;
+constexpr int kLitRoot = 10, kDistRoot = 9;
 constexpr uint32_t kRing = 256;          // token ring (resolved when fewer than 65 slots are free)
 
 // Table entry (16 bits: the tables are what limits the wavefronts a CU can hold, and a lone wavefront
@@ -110,7 +110,54 @@ __device__ __forceinline__ uint64_t gz_peek(const uint8_t* in, uint64_t nbytes, 
     return s ? (lo >> s) | (hi << (64u - s)) : lo;
 }
 
-__constant__ uint8_t kPreOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+typedef const __attribute__((address_space(1))) uint32_t* GzGlobalU32;
+
+__device__ __forceinline__ uint32_t gz_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t gz_uni64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+__device__ __forceinline__ int gz_lane() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
+
+// The stream seen through a register window: lane j holds dword j of 256 bytes of it, read with one
+// coalesced load and good for some 1800 bits of progress; within 512 bytes of the end of the input the
+// bounds-checked gz_peek is used instead.  peek(): 64 bits at a wave-uniform position, by three readlanes.
+struct GzWindow {
+    uint64_t in_addr;
+    long long wpos = 0;  // stream bit position of the window's bit 0 (can be up to 31 below 0)
+    uint32_t win = 0;
+    bool have = false;
+    __device__ __forceinline__ explicit GzWindow(const uint8_t* in) : in_addr(gz_uni64(reinterpret_cast<uint64_t>(in))) {}
+    __device__ __forceinline__ bool covers(uint64_t pos, uint64_t nbytes) const { return (pos >> 3) + 512 <= nbytes; }
+    __device__ __forceinline__ uint32_t seek(uint64_t pos, int lane) {  // -> bit offset of pos in the window
+        if (!have || static_cast<long long>(pos) - wpos > 1800) {
+            const uint64_t al = (in_addr + (pos >> 3)) & ~3ull;
+            win = reinterpret_cast<GzGlobalU32>(al)[lane];
+            wpos = static_cast<long long>(al - in_addr) * 8;
+            have = true;
+        }
+        return static_cast<uint32_t>(static_cast<long long>(pos) - wpos);
+    }
+    __device__ __forceinline__ uint64_t peek(const uint8_t* in, uint64_t nbytes, uint64_t pos, int lane) {
+        pos = gz_uni64(pos);
+        if (!covers(pos, nbytes)) return gz_peek(in, nbytes, pos);
+        const uint32_t o = gz_uni(seek(pos, lane));
+        const uint32_t q = o >> 5, sh = o & 31u;
+        const uint32_t d0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), static_cast<int>(q)));
+        const uint32_t d1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), static_cast<int>(q + 1)));
+        const uint32_t d2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(win), static_cast<int>(q + 2)));
+        const uint64_t lo = ((static_cast<uint64_t>(d1) << 32) | d0) >> sh;
+        const uint64_t hi = sh ? static_cast<uint64_t>(d2) << (64u - sh) : 0ull;
+        return lo | hi;
+    }
+};
+
+// the order in which a dynamic header lists the lengths of the code-length code: 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
+// 12, 3, 13, 2, 14, 1, 15 (five bits each, in two words: no table in memory)
+__device__ __forceinline__ uint32_t gz_pre_order(uint32_t i) {
+    return static_cast<uint32_t>((i < 12u ? 0x22caa324e804a30ull >> (5u * i) : 0x3c2e1346cull >> (5u * (i - 12u))) & 31u);
+}
 
 // Build the lookup table of one alphabet from code lengths lens[0..n): returns false if the set is
 // over-subscribed, or incomplete (allowed only for a distance alphabet with at most one code, as zlib does).
@@ -122,10 +169,10 @@ __device__ bool gz_build(const uint8_t* lens, uint32_t n, uint16_t* table, uint1
     uint32_t count[16];
 #pragma unroll
     for (int l = 0; l < 16; ++l) count[l] = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t l = lens[i];
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {  // 64 symbols at a time, a ballot per code length
+        const uint32_t l = i0 + lane < n ? lens[i0 + lane] : 0u;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) count[k] += (l == static_cast<uint32_t>(k)) ? 1u : 0u;
+        for (int k = 1; k < 16; ++k) count[k] += static_cast<uint32_t>(__popcll(__ballot(l == static_cast<uint32_t>(k))));
     }
     uint32_t used = 0;
     int left = 1;
@@ -245,7 +292,8 @@ __device__ __attribute__((noinline)) uint64_t gz_slow_token(const uint16_t* lit,
 // codes at 0.., distance codes at 288..).  Advances pos; false if the header is not valid.
 __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint64_t nbits, uint64_t& pos,
                                   uint32_t& nlit, uint32_t& ndist, int lane) {
-    uint64_t w = gz_peek(in, nbytes, pos);
+    GzWindow W(in);
+    uint64_t w = W.peek(in, nbytes, pos, lane);
     nlit = (static_cast<uint32_t>(w) & 31u) + 257;
     ndist = (static_cast<uint32_t>(w >> 5) & 31u) + 1;
     const uint32_t ncode = (static_cast<uint32_t>(w >> 10) & 15u) + 4;
@@ -255,11 +303,11 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
     uint32_t pl[19];
 #pragma unroll
     for (int i = 0; i < 19; ++i) pl[i] = 0;
-    w = gz_peek(in, nbytes, pos);
+    w = W.peek(in, nbytes, pos, lane);
     for (uint32_t i = 0; i < ncode; ++i) {
         const uint32_t v = static_cast<uint32_t>(w >> (3 * i)) & 7u;
 #pragma unroll
-        for (int k = 0; k < 19; ++k) pl[k] = (kPreOrder[i] == k) ? v : pl[k];
+        for (int k = 0; k < 19; ++k) pl[k] = (gz_pre_order(i) == static_cast<uint32_t>(k)) ? v : pl[k];
     }
     pos += 3 * ncode;
     // its 7-bit lookup table (small: every lane computes the codes, lane 0 stores)
@@ -307,10 +355,10 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the nlit + ndist code lengths, run-length coded with the code-length code
-    uint32_t i = 0, prev = 0;
+    uint32_t i = 0, prev = 0, kraft_lit = 0, kraft_dst = 0;  // (sums of 2^(15 - length))
     while (i < nlit + ndist) {
         if (pos > nbits) return false;
-        w = gz_peek(in, nbytes, pos);
+        w = W.peek(in, nbytes, pos, lane);
         const uint32_t e = L.pre[static_cast<uint32_t>(w) & 127u];
         const uint32_t l = e >> 5, s = e & 31u;
         if (l == 0) return false;
@@ -332,8 +380,15 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
             pos += 7;
         }
         if (i + rep > nlit + ndist) return false;
-        if (lane == 0)
-            for (uint32_t r = 0; r < rep; ++r) L.lens[(i + r < nlit ? i + r : 288 + (i + r - nlit))] = static_cast<uint8_t>(val);
+        for (uint32_t r = lane; r < rep; r += 64) L.lens[(i + r < nlit ? i + r : 288 + (i + r - nlit))] = static_cast<uint8_t>(val);
+        // An over-subscribed code can be told as soon as it is: what is not a header (vk_gzfind_kernel tests
+        // thousands of those) fails here after a dozen lengths instead of running through all 300.
+        if (val) {
+            const uint32_t in_lit = i >= nlit ? 0u : (i + rep <= nlit ? rep : nlit - i);
+            kraft_lit += in_lit * (32768u >> val);
+            kraft_dst += (rep - in_lit) * (32768u >> val);
+            if (kraft_lit > 32768u || kraft_dst > 32768u) return false;
+        }
         i += rep;
         prev = val;
     }
@@ -358,6 +413,8 @@ struct GzChunk {
     uint64_t out_off, out_cap;   // this chunk's u16 elements in the symbolic buffer (offset and room, in elements)
     uint32_t file_chunk0;        // index of the file's chunk 0 in the chunk arrays
     uint32_t nchunks;            // chunks of the file
+    uint32_t chunk_bytes;        // compressed bytes per chunk (chosen per call: as many chunks as the device holds wavefronts)
+    uint32_t pad_;
 };
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
 constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
@@ -367,6 +424,7 @@ constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded th
 // nothing else reads.  [c][0..1] wall clock at start / end, [2] resolve rounds, [3] tokens, [4..7] cycles in:
 // gz_tokens, -, gz_resolve, block headers and table builds.
 __device__ unsigned long long g_gz_stamps[16384][8];
+__device__ unsigned long long g_gz_find[16384][8];  // vk_gzfind_kernel: wall ticks in all, cycles in full header tests, cycles in verification, candidates tested
 __device__ unsigned long long g_gz_res[16384][4];   // gz_resolve: group set-up, round head + masks, element loop, store drain
 #define GZ_T(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define GZ_ADD(acc, a, b) acc += (b) - (a)
@@ -381,15 +439,7 @@ __device__ unsigned long long g_gz_res[16384][4];   // gz_resolve: group set-up,
 // their innermost loops.  As functions of their own they get a register allocation of their own; what is
 // uniform comes back to scalar registers through readfirstlane on the way in and out.
 typedef __attribute__((address_space(3))) GzLds* GzLdsP;
-typedef const __attribute__((address_space(1))) uint32_t* GzGlobalU32;
 
-__device__ __forceinline__ uint32_t gz_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ uint64_t gz_uni64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
-    return (static_cast<uint64_t>(hi) << 32) | lo;
-}
-__device__ __forceinline__ int gz_lane() { return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))); }
 
 __device__ __attribute__((noinline)) uint64_t gz_peek_tail(const uint8_t* in, uint64_t nbytes, uint64_t p) { return gz_peek(in, nbytes, p); }
 
@@ -917,7 +967,7 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // ---- the chunked path: many wavefronts per file ---------------------------------------------------
 // A gzip file is ONE chain of tokens, but its DEFLATE blocks can be decoded independently once two
 // things are known: where a block starts, and the 32 KiB of text before it (matches reach back that
-// far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every 256 KiB chunk of
+// far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every chunk (128 KiB - 1 MiB) of
 // the compressed file: a cheap test of every bit offset by 64 lanes (block type, code counts, the
 // code-length code must be complete), then the full header parse and table build of the decoder for
 // the few that pass, and for what passes that a decode of the block to its end, which must be followed by
@@ -928,9 +978,11 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // and turns each chunk's last 32 KiB into the next chunk's window, (4) vk_gzfinal_kernel replaces the
 // markers and writes the text.  Anything unexpected (no start found, a chunk that overflows its
 // room, sizes that do not add up) sends the file through vk_inflate_kernel instead.
-constexpr uint32_t kGzChunkBytes = 1u << 18;
+constexpr uint32_t kGzChunkMin = 1u << 17, kGzChunkMax = 1u << 20;  // compressed bytes per chunk
+constexpr uint32_t kGzBigFile = 1u << 19;                             // files at least this large are cut into chunks
+constexpr uint32_t kGzChunkWaves = 28;                                // wavefronts of vk_gzchunk_kernel a CU holds (7 per SIMD)
 
-__global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
+__global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
                                                         uint32_t nchunks_total, uint64_t* __restrict__ starts) {
     __shared__ GzLds L;
     const uint32_t c = blockIdx.x;
@@ -944,18 +996,48 @@ __global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict
     }
     const uint8_t* in = gz + ch.in_off;
     const uint64_t nbytes = ch.in_len, nbits = nbytes * 8;
-    const uint64_t from = static_cast<uint64_t>(j) * kGzChunkBytes * 8;
-    uint64_t to = from + static_cast<uint64_t>(kGzChunkBytes) * 8;
+    const uint64_t from = static_cast<uint64_t>(j) * ch.chunk_bytes * 8;
+    uint64_t to = from + static_cast<uint64_t>(ch.chunk_bytes) * 8;
     if (to + 80 > nbits) to = nbits > 80 ? nbits - 80 : 0;  // (a header needs more bits than that anyway)
     uint64_t found = kGzNone;
+#ifdef VK_GZ_STAMPS
+    unsigned long long f0 = 0, f1 = 0, f2 = 0, acc_full = 0, acc_ver = 0, n_cand = 0, n_slow = 0, acc_slow = 0, n_iter = 0, max_full = 0;
+    const unsigned long long fwall = wall_clock64();
+#endif
+    // (the stream is scanned through a register window, as in gz_tokens: lane j holds dword j of 256 bytes)
+    const uint64_t in_addr = gz_uni64(reinterpret_cast<uint64_t>(in));
+    long long wpos = 0;
+    bool have = false;
+    uint32_t win = 0;
     for (uint64_t p0 = from; p0 < to && found == kGzNone; p0 += 64) {
         const uint64_t p = p0 + lane;
-        const uint64_t w = gz_peek(in, nbytes, p);
+        uint64_t w, w2;  // 64 bits at p, and at p + 17 (the code-length code's lengths)
+        if ((p0 >> 3) + 512 <= nbytes) {
+            if (!have || static_cast<long long>(p0) - wpos > 1800) {
+                const uint64_t al = (in_addr + (p0 >> 3)) & ~3ull;
+                win = reinterpret_cast<GzGlobalU32>(al)[lane];
+                wpos = static_cast<long long>(al - in_addr) * 8;
+                have = true;
+            }
+            const uint32_t o = static_cast<uint32_t>(static_cast<long long>(p0) - wpos) + static_cast<uint32_t>(lane);
+            const int q4 = static_cast<int>((o >> 5) << 2);
+            const uint32_t sh = o & 31u;
+            const uint32_t d0 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4, static_cast<int>(win)));
+            const uint32_t d1 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4 + 4, static_cast<int>(win)));
+            const uint32_t d2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4 + 8, static_cast<int>(win)));
+            const uint32_t d3 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(q4 + 12, static_cast<int>(win)));
+            w = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(d2, d1, sh)) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+            const uint32_t s2 = sh + 17u;  // 17 .. 48
+            const uint32_t a0 = s2 < 32u ? d0 : d1, a1 = s2 < 32u ? d1 : d2, a2 = s2 < 32u ? d2 : d3;
+            w2 = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(a2, a1, s2 & 31u)) << 32) | __builtin_amdgcn_alignbit(a1, a0, s2 & 31u);
+        } else {
+            w = gz_peek(in, nbytes, p);
+            w2 = gz_peek(in, nbytes, p + 17);
+        }
         // not the last block, dynamic codes, at most 286 literal/length and 30 distance codes
         bool cand = p < to && (w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u;
         if (cand) {  // the code-length code must be complete: sum of 2^-len = 1
             const uint32_t ncode = (static_cast<uint32_t>(w >> 13) & 15u) + 4;
-            const uint64_t w2 = gz_peek(in, nbytes, p + 17);
             uint32_t kraft = 0;
             for (uint32_t i = 0; i < ncode; ++i) {
                 const uint32_t v = static_cast<uint32_t>(w2 >> (3 * i)) & 7u;
@@ -963,22 +1045,33 @@ __global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict
             }
             cand = kraft == 128u;
         }
+#ifdef VK_GZ_STAMPS
+        ++n_iter;
+#endif
         unsigned long long b = __ballot(cand);
         while (b && found == kGzNone) {  // the full test, by the whole wave, in stream order
             const int l = __builtin_ctzll(b);
             b &= b - 1;
             uint64_t pos = p0 + l + 3;
             uint32_t nlit, ndist;
-            if (!(gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
-                  gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
-                  gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane)))
-                continue;
+            GZ_T(f0);
+            const bool full = gz_dynamic_header(L, in, nbytes, nbits, pos, nlit, ndist, lane) &&
+                              gz_build<true>(L.lens, nlit, L.lit, L.lit_sym, L.lit_cnt, lane) &&
+                              gz_build<false>(L.lens + 288, ndist, L.dst, L.dst_sym, L.dst_cnt, lane);
+            GZ_T(f1);
+            GZ_ADD(acc_full, f0, f1);
+#ifdef VK_GZ_STAMPS
+            ++n_cand;
+            if (f1 - f0 > 30000) { ++n_slow; acc_slow += f1 - f0; }
+            if (f1 - f0 > max_full) max_full = f1 - f0;
+#endif
+            if (!full) continue;
             // Random bits pass all that about once in 10^8 positions, i.e. in one chunk of a hundred, and a false
             // start costs the chunk before it a second chunk's worth of decoding while every other wavefront
             // has finished.  So: decode the candidate block to its end (tokens dropped) and ask for a
             // plausible block header behind it.  A block too long to check (2 chunks) is taken on trust.
             bool ok = true, at_end = false;
-            const uint64_t limit = pos + 16ull * kGzChunkBytes;
+            const uint64_t limit = pos + 16ull * ch.chunk_bytes;
             for (;;) {
                 const GzRun r = gz_tokens((GzLdsP)(&L), in, nbytes, pos, 0);
                 pos = gz_uni64(r.pos);
@@ -1009,13 +1102,21 @@ __global__ __launch_bounds__(64) void vk_gzfind_kernel(const uint8_t* __restrict
                     }
                 }
             }
+            GZ_T(f2);
+            GZ_ADD(acc_ver, f1, f2);
             if (ok) found = p0 + l;
         }
     }
+#ifdef VK_GZ_STAMPS
+    if (lane == 0 && c < 16384) {
+        g_gz_find[c][0] = wall_clock64() - fwall; g_gz_find[c][1] = acc_full; g_gz_find[c][2] = acc_ver; g_gz_find[c][3] = n_cand;
+        g_gz_find[c][4] = n_slow; g_gz_find[c][5] = acc_slow; g_gz_find[c][6] = max_full; g_gz_find[c][7] = n_iter;
+    }
+#endif
     if (lane == 0) starts[c] = found;
 }
 
-__global__ __launch_bounds__(64, 6) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
+__global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
                                                          const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
                                                          const uint64_t* __restrict__ starts,
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
@@ -1092,9 +1193,39 @@ __global__ __launch_bounds__(256) void vk_gzfinal_kernel(const uint16_t* __restr
     const uint16_t* e = sym + it.sym_off;
     const uint8_t* w = win_in + static_cast<uint64_t>(k) * 32768;
     uint8_t* out = text + it.text_off;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; i < it.len; i += static_cast<uint64_t>(gridDim.x) * 256) {
+    auto one = [&](uint64_t i) {
         const uint32_t x = e[i];
         out[i] = static_cast<uint8_t>(x < 0x8000u ? x : w[x & 0x7FFFu]);
+    };
+    // eight elements per thread where the text is 8-byte aligned (16 bytes in, 8 bytes out); the few before and
+    // after that by the first threads of block 0
+    const uint64_t head = (8u - (reinterpret_cast<uint64_t>(out) & 7u)) & 7u;
+    const uint64_t h = head < it.len ? head : it.len;
+    const uint64_t groups = (it.len - h) / 8, tail0 = h + groups * 8;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < h) one(threadIdx.x);
+        if (tail0 + threadIdx.x < it.len && threadIdx.x < 8) one(tail0 + threadIdx.x);
+    }
+    for (uint64_t g = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x; g < groups; g += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t i = h + g * 8;
+        uint4 v;
+        __builtin_memcpy(&v, e + i, 16);
+        const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t b[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b[2 * q] = x[q] & 0xFFFFu;
+            b[2 * q + 1] = x[q] >> 16;
+        }
+        if ((v.x | v.y | v.z | v.w) & 0x80008000u) {  // a reference into the window among them
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (b[q] & 0x8000u) b[q] = w[b[q] & 0x7FFFu];
+        }
+        uint2 o;
+        o.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        *reinterpret_cast<uint2*>(out + i) = o;
     }
 }
 

@@ -77,6 +77,8 @@ struct vk_ctx {
     uint8_t* d_gzcrc = nullptr;   // ... CRC-32 jobs, operators, segment values
     size_t gzcrc_cap = 0;
     bool gz_no_chunks = false;    // VKIMG_GZ_NO_CHUNKS=1: every file through the one-wavefront kernel (tests, A/B timing)
+    uint32_t gz_chunk_bytes = 0;  // VKIMG_GZ_CHUNK_BYTES: fixed chunk size of the chunked inflate (0 = fitted to the device)
+    int num_cus = 256;
     size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
@@ -283,10 +285,16 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         ctx->image_sort_only = e && e[0] == '1';
         const char* g = getenv("VKIMG_GZ_NO_CHUNKS");
         ctx->gz_no_chunks = g && g[0] == '1';
+        const char* cb = getenv("VKIMG_GZ_CHUNK_BYTES");
+        if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
     }
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return VK_EHIP; }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
     if (!own_stream) {
         ctx->stream = static_cast<hipStream_t>(stream);  // NULL = the device's default stream
     } else {
@@ -583,24 +591,38 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
     for (uint32_t i = 0; i < nfiles; ++i) {
         out_lengths[i] = 0;
         status[i] = 0;
-        if (!ctx->gz_no_chunks && gz_lengths[i] >= 2ull * kGzChunkBytes) big.push_back(i);
+        if (!ctx->gz_no_chunks && gz_lengths[i] >= kGzBigFile) big.push_back(i);
         else direct.push_back(i);
     }
     if (!big.empty()) {
         std::vector<GzChunk> chunks;
         std::vector<uint32_t> chunk0(big.size());
         uint64_t sym_total = 0;
+        // Chunk size: the decoder is latency bound, its throughput is the number of wavefronts at work, so
+        // the call's compressed bytes are cut into as many chunks as the device holds wavefronts of the chunk
+        // kernel (one round of them), within 128 KiB .. 1 MiB per chunk.
+        uint32_t chunk_bytes = ctx->gz_chunk_bytes;
+        if (chunk_bytes == 0) {
+            uint64_t big_total = 0;
+            for (uint32_t i : big) big_total += gz_lengths[i];
+            const uint64_t slots = static_cast<uint64_t>(ctx->num_cus) * kGzChunkWaves;
+            const uint64_t spare = slots / 32 + big.size();  // (every file ends in a partial chunk)
+            uint64_t per = big_total / (slots > spare ? slots - spare : 1);
+            per = (per + 16383) / 16384 * 16384;
+            chunk_bytes = per < kGzChunkMin ? kGzChunkMin : (per > kGzChunkMax ? kGzChunkMax : static_cast<uint32_t>(per));
+        }
+        if (chunk_bytes < 65536u) chunk_bytes = 65536u;
         for (size_t b = 0; b < big.size(); ++b) {
             const uint32_t i = big[b];
-            const uint32_t nch = static_cast<uint32_t>((gz_lengths[i] + kGzChunkBytes - 1) / kGzChunkBytes);
-            // room per chunk (u16 elements): twice what the file's overall ratio predicts for 256 KiB, at least 8x
+            const uint32_t nch = static_cast<uint32_t>((gz_lengths[i] + chunk_bytes - 1) / chunk_bytes);
+            // room per chunk (u16 elements): twice what the file's overall ratio predicts for a chunk, at least 8x
             double ratio = static_cast<double>(out_caps[i]) / static_cast<double>(gz_lengths[i]);
             if (ratio < 4.0) ratio = 4.0;
-            uint64_t cap = static_cast<uint64_t>(2.0 * ratio * kGzChunkBytes) + 65536;
+            uint64_t cap = static_cast<uint64_t>(2.0 * ratio * chunk_bytes) + 65536;
             if (cap > (1ull << 25)) cap = 1ull << 25;
             chunk0[b] = static_cast<uint32_t>(chunks.size());
             for (uint32_t j = 0; j < nch; ++j) {
-                chunks.push_back(GzChunk{gz_offsets[i], gz_lengths[i], sym_total, cap, chunk0[b], nch});
+                chunks.push_back(GzChunk{gz_offsets[i], gz_lengths[i], sym_total, cap, chunk0[b], nch, chunk_bytes, 0});
                 sym_total += cap;
             }
         }
@@ -805,6 +827,9 @@ int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t np
 }
 
 #ifdef VK_GZ_STAMPS
+int vk_debug_read_gz_find(unsigned long long* out, uint32_t nchunks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gz_find), static_cast<size_t>(nchunks) * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
 int vk_debug_read_gz_res(unsigned long long* out, uint32_t nchunks, int clear) {
     if (clear) {
         static unsigned long long zeros[16384 * 4];

@@ -283,3 +283,30 @@ def test_inflate_verifies_the_crc_of_single_member_files(engines):
     two = with_crc(gz(small), 5) + gz(small[:1000])
     got, status, _, _ = run(eng, [two], caps=[len(small) + 1000])
     assert status[0] == 0 and got[0] == small + small[:1000]
+
+
+def test_inflate_chunk_sizes_and_false_block_starts(monkeypatch):
+    """The chunked path with the chunk size forced (VKIMG_GZ_CHUNK_BYTES, read when a context is made) from 64 KiB
+    -- smaller than some DEFLATE blocks, so chunks without any block start occur -- to 1 MiB: same text every
+    time.  The input carries, inside stored blocks, bytes that look like the start of a dynamic-codes block (the
+    header of a real one, copied): the finder must not settle on them (it decodes a candidate block to its end
+    and wants another block header there), and whatever it settles on, the text must come out right."""
+    from varkoder_amd.engine import ImageEngine
+    rng = np.random.default_rng(23)
+    fq = synth.sample_fastq(40, 60000, 150, dist=1).tobytes()                       # 19 MB
+    real = gz(fq[:3_000_000], 6, wbits=-15)                                          # raw deflate: begins with a dynamic header
+    decoy = real[:4096]
+    noise = rng.integers(0, 256, size=1_500_000, dtype=np.uint8).tobytes()
+    spiked = b"".join(noise[i:i + 50_000] + decoy for i in range(0, len(noise), 50_000))
+    texts = [fq, fq[:5_000_000] + spiked + fq[5_000_000:9_000_000] + spiked[:300_000] + fq[9_000_000:]]
+    files = [gz(texts[0], 6), gz(texts[1], 6)]
+    assert all(len(f) >= (1 << 19) for f in files)
+    for cb in (1 << 16, 1 << 17, 3 << 16, 1 << 20):
+        monkeypatch.setenv("VKIMG_GZ_CHUNK_BYTES", str(cb))
+        eng = ImageEngine(k=7, mapping="cgr", device=0)
+        try:
+            got, status, _, _ = run(eng, files, caps=[len(t) for t in texts])
+        finally:
+            eng.close()
+        assert status.tolist() == [0, 0], cb
+        assert got[0] == texts[0] and got[1] == texts[1], cb

@@ -413,7 +413,7 @@ struct GzChunk {
     uint64_t out_off, out_cap;   // this chunk's u16 elements in the symbolic buffer (offset and room, in elements)
     uint32_t file_chunk0;        // index of the file's chunk 0 in the chunk arrays
     uint32_t nchunks;            // chunks of the file
-    uint32_t chunk_bytes;        // compressed bytes per chunk (chosen per call: as many chunks as the device holds wavefronts)
+    uint32_t chunk_bytes;        // compressed bytes per chunk (chosen per call, vk_inflate_device)
     uint32_t pad_;
 };
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // ---- the chunked path: many wavefronts per file ---------------------------------------------------
 // A gzip file is ONE chain of tokens, but its DEFLATE blocks can be decoded independently once two
 // things are known: where a block starts, and the 32 KiB of text before it (matches reach back that
-// far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every chunk (128 KiB - 1 MiB) of
+// far).  (1) vk_gzfind_kernel looks for the first dynamic-codes block header in every chunk (128 or 256 KiB) of
 // the compressed file: a cheap test of every bit offset by 64 lanes (block type, code counts, the
 // code-length code must be complete), then the full header parse and table build of the decoder for
 // the few that pass, and for what passes that a decode of the block to its end, which must be followed by
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // and turns each chunk's last 32 KiB into the next chunk's window, (4) vk_gzfinal_kernel replaces the
 // markers and writes the text.  Anything unexpected (no start found, a chunk that overflows its
 // room, sizes that do not add up) sends the file through vk_inflate_kernel instead.
-constexpr uint32_t kGzChunkMin = 1u << 17, kGzChunkMax = 1u << 20;  // compressed bytes per chunk
+constexpr uint32_t kGzChunkMin = 1u << 17;                            // compressed bytes per chunk: this, or twice this
 constexpr uint32_t kGzBigFile = 1u << 19;                             // files at least this large are cut into chunks
 constexpr uint32_t kGzChunkWaves = 28;                                // wavefronts of vk_gzchunk_kernel a CU holds (7 per SIMD)
 

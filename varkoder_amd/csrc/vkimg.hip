@@ -598,18 +598,15 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         std::vector<GzChunk> chunks;
         std::vector<uint32_t> chunk0(big.size());
         uint64_t sym_total = 0;
-        // Chunk size: the decoder is latency bound, its throughput is the number of wavefronts at work, so
-        // the call's compressed bytes are cut into as many chunks as the device holds wavefronts of the chunk
-        // kernel (one round of them), within 128 KiB .. 1 MiB per chunk.
+        // Chunk size: 128 KiB gives a small call the most wavefronts (8 files of 24 MB: 48 ms against 72 ms with
+        // 256 KiB); once there are more chunks than the device holds wavefronts, throughput no longer
+        // depends on it (measured flat from 128 to 320 KiB) and 256 KiB halves the per-chunk work of the finder.
         uint32_t chunk_bytes = ctx->gz_chunk_bytes;
         if (chunk_bytes == 0) {
             uint64_t big_total = 0;
             for (uint32_t i : big) big_total += gz_lengths[i];
             const uint64_t slots = static_cast<uint64_t>(ctx->num_cus) * kGzChunkWaves;
-            const uint64_t spare = slots / 32 + big.size();  // (every file ends in a partial chunk)
-            uint64_t per = big_total / (slots > spare ? slots - spare : 1);
-            per = (per + 16383) / 16384 * 16384;
-            chunk_bytes = per < kGzChunkMin ? kGzChunkMin : (per > kGzChunkMax ? kGzChunkMax : static_cast<uint32_t>(per));
+            chunk_bytes = big_total / kGzChunkMin > slots ? 2 * kGzChunkMin : kGzChunkMin;
         }
         if (chunk_bytes < 65536u) chunk_bytes = 65536u;
         for (size_t b = 0; b < big.size(); ++b) {

@@ -827,7 +827,14 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
 
     // Move the full blocks of every queue (nb = 0..4 of them, n = its fill in bytes) to the arena.
     // All lanes call it; nb and n are the same in the four lanes of a queue.
-    auto drain_all = [&](uint32_t n, uint32_t nb) __attribute__((always_inline)) {
+    auto drain_all = [&](uint32_t n, uint32_t nb_) __attribute__((always_inline)) {
+        // (the queue's addresses are worked out again here from an opaque copy of the lane number: kept in
+        // registers across the piece loop they were spilled, and every reload from scratch came with a wait for
+        // all outstanding stores -- the blocks of one drain then went out one store round trip at a time)
+        uint32_t lz = static_cast<uint32_t>(lane), nb = nb_;
+        asm volatile("" : "+v"(lz));
+        const uint32_t q = lz >> 2, sub = lz & 3u;
+        uint8_t* const qdata = ldsb + kLdsQueues + (static_cast<uint32_t>(wave) * kQueues + q) * kQueueBytes;
         uint32_t run = qrun[q], used = qused[q];
         const bool need = nb != 0u && used + nb > kRunBlocks;  // the blocks of one drain stay in one run
         if (need && sub == 0 && used <= kRunBlocks) hdrs[run] = 0x80000000u | (used << 8) | q;  // close the old run

@@ -729,6 +729,8 @@ struct BucketParams {
     uint32_t* hdrs;      // [nsamples][runs_cap] 0x80000000 | filled blocks << 8 | bucket, 0 = never closed
     uint8_t* arena;      // [nsamples][runs_cap][kRunBytes]
     uint32_t* bucket_hist;  // [nsamples][16][2 * 4^K / 16] pass B's counters, merged into the histogram by pass C
+    uint32_t* bsize;     // [nsamples][16] blocks of each bucket stream in the arena (added up as runs are closed)
+    uint32_t* order;     // [nsamples * 16] pass B's (sample, bucket) jobs, the large ones first
     uint32_t runs_cap;
 };
 
@@ -837,7 +839,10 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
         uint8_t* const qdata = ldsb + kLdsQueues + (static_cast<uint32_t>(wave) * kQueues + q) * kQueueBytes;
         uint32_t run = qrun[q], used = qused[q];
         const bool need = nb != 0u && used + nb > kRunBlocks;  // the blocks of one drain stay in one run
-        if (need && sub == 0 && used <= kRunBlocks) hdrs[run] = 0x80000000u | (used << 8) | q;  // close the old run
+        if (need && sub == 0 && used <= kRunBlocks) {  // close the old run
+            hdrs[run] = 0x80000000u | (used << 8) | q;
+            atomicAdd(&bp.bsize[s * kQueues + q], used);
+        }
         uint32_t nrun = 0;
         if (need && sub == 0) nrun = atomicAdd(cursor, 1u);
         nrun = quad_bcast0(nrun);
@@ -1049,9 +1054,36 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
         const uint16_t* q16 = reinterpret_cast<const uint16_t*>(qdata);
         for (uint32_t i = sub; i < n / 2u; i += 4u) count_entry_direct<K>(hist_s, q, q16[i]);
         const uint32_t used = qused[q];
-        if (sub == 0 && used <= kRunBlocks && used != 0u) hdrs[qrun[q]] = 0x80000000u | (used << 8) | q;
+        if (sub == 0 && used <= kRunBlocks && used != 0u) {
+            hdrs[qrun[q]] = 0x80000000u | (used << 8) | q;
+            atomicAdd(&bp.bsize[s * kQueues + q], used);
+        }
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+}
+
+// Between pass A and pass B: the (sample, bucket) jobs of pass B ordered by size class (the power of two of
+// their block count), largest first.  One workgroup of pass B fills a CU (128 KB histogram), a launch is six
+// rounds of them, and with a skewed base composition some bucket streams are four times the average: in
+// (sample, bucket) order the launch ended with one of those running alone (3.9 -> 6.3 ms on GC-rich data).
+// A counting sort over 33 classes by one workgroup; order within a class is whatever the atomics make it.
+__global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, uint32_t njobs) {
+    __shared__ uint32_t cnt[33], first[33];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 33) cnt[tid] = 0u;
+    __syncthreads();
+    auto cls = [](uint32_t blocks) { return blocks ? 32u - static_cast<uint32_t>(__builtin_clz(blocks)) : 0u; };  // 0 .. 32
+    for (uint32_t j = tid; j < njobs; j += 1024) atomicAdd(&cnt[cls(bp.bsize[j])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (int c = 32; c >= 0; --c) {
+            first[c] = at;
+            at += cnt[c];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < njobs; j += 1024) bp.order[atomicAdd(&first[cls(bp.bsize[j])], 1u)] = j;
 }
 
 // Pass B: one workgroup per (sample, bucket) replays the runs of its bucket into a 2 x 4^K/16-bin
@@ -1069,7 +1101,8 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     __shared__ uint32_t hist[BINS];
     __shared__ uint32_t list[kList];
     __shared__ uint32_t nlist;
-    const uint32_t s = blockIdx.x / kQueues, q = blockIdx.x % kQueues;
+    const uint32_t job = bp.order[blockIdx.x];  // large streams first (vk_bucket_order_kernel)
+    const uint32_t s = job / kQueues, q = job % kQueues;
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
     uint32_t nruns = bp.cursors[s];

@@ -174,7 +174,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
     if (runs >= (1u << 24)) return VK_EINVAL;             // a run number travels in 24 bits (64 GiB of entries per sample)
     constexpr size_t kBucketHistBytes = static_cast<size_t>(kQueues) * (2u << (2 * K - 4)) * sizeof(uint32_t);  // pass B -> merge
-    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + kBucketHistBytes;
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + 2 * kQueues * sizeof(uint32_t) + kBucketHistBytes;
     // never plan for more than three quarters of what is free (plus what this context already holds)
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -184,8 +184,9 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     uint32_t batch = static_cast<uint32_t>(budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
-    // workspace: cursors[batch] | hdrs[batch][runs] | bucket histograms[batch][16][2 * 4^K / 16] | arena[batch][runs][4 KiB]
-    const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs)) * sizeof(uint32_t) + 255) / 256 * 256;
+    // workspace: cursors[batch] | hdrs[batch][runs] | bucket sizes[batch][16] | job order[batch * 16] |
+    //            bucket histograms[batch][16][2 * 4^K / 16] | arena[batch][runs][4 KiB]
+    const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs + 2 * kQueues)) * sizeof(uint32_t) + 255) / 256 * 256;
     const size_t bh_bytes = static_cast<size_t>(batch) * kBucketHistBytes;
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap,
                     head_bytes + bh_bytes + static_cast<size_t>(batch) * runs * kRunBytes);
@@ -193,6 +194,8 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     BucketParams bp;
     bp.cursors = ctx->d_spill;
     bp.hdrs = ctx->d_spill + batch;
+    bp.bsize = bp.hdrs + static_cast<size_t>(batch) * runs;
+    bp.order = bp.bsize + static_cast<size_t>(batch) * kQueues;
     bp.bucket_hist = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes);
     bp.arena = reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes + bh_bytes;
     bp.runs_cap = static_cast<uint32_t>(runs);
@@ -216,6 +219,8 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                d_fastq, d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
                                ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, SubParams{});
         }
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(vk_bucket_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bp, n * kQueues);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());

@@ -198,12 +198,19 @@ def end_to_end(eng, args):
             # one untimed pass first: staging buffers and device workspaces are allocated once per process
             pipeline.fastqs_to_images(files, tmp / ("warm_" + name), k=args.k, mapping_code=args.mapping,
                                       io_threads=threads, engine=eng, batch_bytes=bb)
-            t0 = time.perf_counter()
-            stats = pipeline.fastqs_to_images(files, dst, k=args.k, mapping_code=args.mapping, io_threads=threads,
-                                              engine=eng, batch_bytes=bb)
-            dt = time.perf_counter() - t0
+            # two timed passes (the second into a fresh folder); the faster one is quoted, both are listed
+            passes = []
+            for rep in range(2):
+                if rep:
+                    dst = tmp / ("img2_" + name)
+                t0 = time.perf_counter()
+                stats = pipeline.fastqs_to_images(files, dst, k=args.k, mapping_code=args.mapping, io_threads=threads,
+                                                  engine=eng, batch_bytes=bb)
+                passes.append(time.perf_counter() - t0)
+            dst = tmp / ("img_" + name)
+            dt = min(passes)
             ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
-            out[name] = {"seconds": dt, "gbases_per_s": bases / dt / 1e9, "files_per_s": nfiles / dt,
+            out[name] = {"seconds": dt, "passes_s": passes, "gbases_per_s": bases / dt / 1e9, "files_per_s": nfiles / dt,
                          "file_bytes": moved, "file_gb_per_s": moved / dt / 1e9, "text_gb_per_s": text_bytes / dt / 1e9,
                          "batch_bytes": bb, "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png")))}
         # the two routes must give the same images
@@ -222,8 +229,9 @@ def end_to_end(eng, args):
             dev.copy_(pin, non_blocking=True)
         torch.cuda.synchronize()
         out["pcie_h2d_gb_per_s_pinned_1GiB"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
-        out["note"] = ("files -> PNGs, page cache warm, one GPU; .fq.gz files cross PCIe compressed and are "
-                       "inflated in HBM (vk_inflate_device)")
+        out["note"] = ("files -> PNGs, page cache warm, one GPU, the faster of two passes; .fq.gz files stay compressed in the "
+                       "pinned staging buffer, the inflate kernels read them over PCIe and write the text to HBM "
+                       "(vk_inflate_device)")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out

@@ -116,8 +116,10 @@ int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* o
                              uint32_t* d_status, uint8_t* d_img);
 
 /* Replaces the gzip reader inside dsk (`-file IN.fq.gz`, commands/image.py:771-790; the files are
- * written by split_fastq, :696-708): inflates nfiles gzip files resident in HBM,
- * d_gz[gz_offsets[i] .. +gz_lengths[i]), into d_out[out_offsets[i] ..), at most out_caps[i] bytes each
+ * written by split_fastq, :696-708): inflates nfiles gzip files,
+ * d_gz[gz_offsets[i] .. +gz_lengths[i]), into d_out[out_offsets[i] ..), at most out_caps[i] bytes each.
+ * d_gz is memory the device can read: HBM, or pinned host memory (hipHostMalloc) -- the kernels then read the
+ * compressed bytes over PCIe where they lie (twice: block-start finder and decoder) and no copy is needed
  * (single-member files: the little-endian u32 in the file's last four bytes is the text length).
  * Multi-member files and zero padding after the last member are accepted.  out_lengths[i] (host)
  * receives the bytes written and status[i] (host) the VK_GZ_* bits; the call synchronises.

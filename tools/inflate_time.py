@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of vk_inflate_device: N gzip files of synthetic FASTQ (zlib level L) resident in HBM ->
-text in HBM.  python tools/inflate_time.py [nfiles] [reads] [level]"""
+text in HBM.  python tools/inflate_time.py [nfiles] [reads] [level] [pinned]
+(a fourth argument: the compressed bytes stay in pinned host memory and the kernels read them over PCIe)"""
 import sys
 import time
 import zlib
@@ -36,7 +37,7 @@ for f in files:
 host = np.zeros(pos + 16, dtype=np.uint8)
 for o, f in zip(offs, files):
     host[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
-dev = torch.from_numpy(host).cuda()
+dev = torch.from_numpy(host).pin_memory() if len(sys.argv) > 4 else torch.from_numpy(host).cuda()
 ooffs, pos = [], 0
 for n in tl:
     ooffs.append(pos)

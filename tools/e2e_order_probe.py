@@ -36,9 +36,11 @@ with ThreadPoolExecutor(16) as ex:
     list(ex.map(write, range(nfiles)))
 del host
 order = (("fq_gz", gz, 16 << 30), ("plain_text", plain, 2 << 30))
-if len(sys.argv) < 2:
+if 'gz_first' not in sys.argv:
     order = order[::-1]
 for name, files, bb in order + order:
+    if 'fresh' in sys.argv:
+        eng.__dict__.pop('_pinned_slots', None)  # a new staging buffer for every kind of input
     for rep in range(3):
         t0 = time.perf_counter()
         pipeline.fastqs_to_images(files, tmp / f"img_{name}_{rep}_{time.time_ns()}", k=7, mapping_code="varKode", io_threads=16, engine=eng,

@@ -178,7 +178,192 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
     return 0;
 }
 
+// csrc/vk_count.h vk_count_dense_kernel, sequentially: line pass per piece, the granule list, rounds of
+// 64 listed granules, the flush before a piece that takes the general path, context from the previous
+// listed granule.  `stats` (optional): [0] pieces on the fast path, [1] pieces in all, [2] rounds,
+// [3] granules counted in rounds.
+template <int K>
+int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status, uint64_t* stats) {
+    const uint32_t ncode = 1u << (2 * K);
+    std::vector<uint32_t> raw(ncode, 0u);
+    const uint64_t nblk = (len + 63) >> 6;
+    const uint64_t bwg = (nblk + parts - 1) / parts;
+    const uint64_t bw = (bwg + kWaves - 1) / kWaves;
+    uint32_t st = 0, prev_end = 0;
+    if (len && s[0] != '@') st |= 1u;
+    {
+        uint32_t seen = 0;
+        const uint64_t lim = len < 65536 ? len : 65536;
+        for (uint64_t p = 0; p < lim; ++p)
+            if (s[p] == '\n' && ++seen == 2) {
+                if (p + 1 < len && s[p + 1] != '+') st |= 1u;
+                break;
+            }
+    }
+    for (uint32_t part = 0; part < parts; ++part)
+        for (int wave = 0; wave < kWaves; ++wave) {
+            uint64_t blk0 = (uint64_t)part * bwg + (uint64_t)wave * bw;
+            uint64_t blk1 = (uint64_t)part * bwg + std::min<uint64_t>((uint64_t)(wave + 1) * bw, bwg);
+            if (blk1 > nblk) blk1 = nblk;
+            if (blk0 >= blk1) continue;
+            const uint64_t w0 = blk0 << 6, w1 = std::min<uint64_t>(blk1 << 6, len);
+            const uint32_t ph0 = w0 ? sync_phase(s, w0, len) : 0u;
+            if (ph0 != prev_end) st |= 2u;
+            const bool has_pre = w0 != 0;
+            const uint64_t o0 = has_pre ? w0 - 64 : 0;
+            const uint64_t span = w1 - o0;
+            const uint32_t npieces = (uint32_t)((span + kPiece - 1) / kPiece);
+            // what the kernel's buffer descriptor returns: bytes of [o0, w1 rounded up to 16), zero beyond;
+            // bytes at or beyond w1 inside the last granule are whatever the buffer holds (here: the file's
+            // own bytes or padding) -- only the last piece clips them, and it takes the general path.
+            auto byte_at = [&](uint64_t rel) -> uint8_t {
+                const uint64_t lim = (span + 15) & ~15ull;
+                return rel < lim ? s[o0 + rel] : 0;  // s is padded by 64 readable bytes
+            };
+            uint32_t ctx_c = 0, ctx_bad = 0x55555555u, pph = 0, npend = 0, pend_it = 0;
+            std::vector<uint16_t> dlist(320, 0);
+            auto round = [&](uint32_t first, uint32_t n, uint32_t ref) {
+                uint32_t C[64], bad[64];
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t dsc = lane < n ? dlist[first + lane] : vkl::kDescEndAt0;
+                    const uint32_t older = ((dsc >> 8) ^ ref) & 1u;
+                    const uint64_t rel = (uint64_t)(ref - 1u) * kPiece + ((dsc & 0xFFu) << 4) + (older ? 0u : (uint32_t)kPiece);
+                    uint32_t a[4];
+                    uint8_t b[16];
+                    for (int i = 0; i < 16; ++i) b[i] = byte_at(rel + i);
+                    memcpy(a, b, 16);
+                    uint32_t IV;
+                    vkl::classify_granule(a[0], a[1], a[2], a[3], C[lane], IV);
+                    bad[lane] = (IV | ~vkl::desc_seq_mask(dsc)) & 0x55555555u;
+                }
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t badh = lane ? bad[lane - 1] : ctx_bad, ch = lane ? C[lane - 1] : ctx_c;
+                    const uint32_t ok = vkl::ok_mask1<K>(badh, bad[lane]);
+                    vkl::windows1<K>(ch, C[lane], ok, [&](uint32_t a4) { raw[a4 >> 2]++; });
+                }
+                ctx_bad = bad[n - 1];
+                ctx_c = C[n - 1];
+                if (stats) { stats[2]++; stats[3] += n; }
+            };
+            for (uint32_t it = 0; it < npieces; ++it) {
+                uint8_t piece[kPiece];
+                for (int i = 0; i < kPiece; ++i) {
+                    const uint64_t rel = (uint64_t)it * kPiece + i;
+                    piece[i] = rel < span ? s[o0 + rel] : 0;  // the registers: the last piece is clipped at w1
+                }
+                if (stats) stats[1]++;
+                bool fast = it != 0 && it + 1 != npieces;
+                uint32_t sp[64], ep[64], total = 0;
+                if (fast) {
+                    for (int lane = 0; lane < 64 && fast; ++lane) {
+                        uint32_t d[16];
+                        memcpy(d, piece + 64 * lane, 64);
+                        if (vkl::ascii_or(d)) fast = false;
+                    }
+                }
+                if (fast) {
+                    uint32_t excl = 0;
+                    bool all_plain = true;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        uint32_t d[16], mlo, mhi;
+                        memcpy(d, piece + 64 * lane, 64);
+                        vkl::newline_mask64(d, mlo, mhi);
+                        const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
+                        const uint32_t lph = (pph + excl) & 3u;
+                        excl += c;
+                        const bool plain = vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane]);
+                        const bool both = (sp[lane] >> 4) == (ep[lane] >> 4) && (sp[lane] & 15u) != 0u;
+                        if (!plain || both) all_plain = false;
+                    }
+                    total = excl;
+                    fast = all_plain;
+                }
+                if (npend != 0 && (!fast || pend_it + 1 < it)) {
+                    round(0, npend, it - 1);
+                    npend = 0;
+                }
+                if (fast) {
+                    if (stats) stats[0]++;
+                    if (npend == 0) pend_it = it;
+                    uint32_t at = npend;
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        const uint32_t sl = sp[lane], el = ep[lane];
+                        if (sl >= 64) continue;
+                        const uint32_t gs = sl >> 4, ge = std::min(el, 63u) >> 4;
+                        for (uint32_t g = gs; g <= ge; ++g) dlist[at++] = (uint16_t)vkl::granule_desc(lane, g, it & 1u, sl, el);
+                    }
+                    const uint32_t tot = at, rounds = tot >> 6;
+                    for (uint32_t r = 0; r < rounds; ++r) round(r << 6, 64, it);
+                    const uint32_t left = tot & 63u;
+                    if (rounds) {
+                        for (uint32_t j = 0; j < left; ++j) dlist[j] = dlist[(rounds << 6) + j];
+                        pend_it = it;
+                    }
+                    npend = left;
+                    pph += total;
+                    continue;
+                }
+                // general path
+                vkl::LaneBits lb[64];
+                uint32_t c[64];
+                bool non_ascii = false;
+                for (int lane = 0; lane < 64; ++lane) {
+                    uint32_t d[16];
+                    memcpy(d, piece + 64 * lane, 64);
+                    non_ascii |= vkl::has_non_ascii(d);
+                }
+                total = 0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    uint32_t d[16];
+                    memcpy(d, piece + 64 * lane, 64);
+                    c[lane] = non_ascii ? vkl::classify<false>(d, lb[lane]) : vkl::classify<true>(d, lb[lane]);
+                    total += c[lane];
+                }
+                if (it == 0) pph = has_pre ? ph0 - c[0] : 0u;
+                bool any_gt3 = false, any_eq4 = false;
+                for (int lane = 0; lane < 64; ++lane) { any_gt3 |= c[lane] > 4; any_eq4 |= c[lane] > 3; }
+                uint32_t excl = 0;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const uint32_t lph = (pph + excl) & 3u;
+                    excl += c[lane];
+                    uint32_t s_raw = 0;
+                    vkl::Mask128 seq = any_gt3 ? vkl::seq_mask_general(lb[lane].NL, lph)
+                                       : any_eq4 ? vkl::seq_mask_fast4(lb[lane].NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw)
+                                                 : vkl::seq_mask_count(lb[lane].NL, lph);
+                    uint32_t bad[4], ok[4];
+                    vkl::bad_mask(lb[lane], seq, bad);
+                    const uint32_t badh = ctx_bad, ch = ctx_c;
+                    ctx_bad = bad[3];
+                    ctx_c = lb[lane].C[3];
+                    vkl::ok_mask<K>(badh, bad, ok);
+                    if (it == 0 && lane == 0 && has_pre) ok[0] = ok[1] = ok[2] = ok[3] = 0;
+                    vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; }, [] {});
+                }
+                pph += total;
+            }
+            if (npend != 0) return 2;  // cannot happen: the last piece of a range takes the general path
+            prev_end = pph & 3u;
+        }
+    if (len) {
+        uint32_t want = s[len - 1] == '\n' ? 0u : 3u;
+        if (prev_end != want) st |= 2u;
+    }
+    for (uint32_t i = 0; i < ncode; ++i) hist[pair_reverse(i, K)] += raw[i];
+    *status = st;
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int emul_count_dense(const uint8_t* s, uint64_t len, int k, uint32_t parts, uint32_t* hist, uint32_t* status,
+                                uint64_t* stats) {
+    switch (k) {
+        case 5: return count_dense_impl<5>(s, len, parts, hist, status, stats);
+        case 6: return count_dense_impl<6>(s, len, parts, hist, status, stats);
+        case 7: return count_dense_impl<7>(s, len, parts, hist, status, stats);
+        default: return 1;
+    }
+}
 
 extern "C" int emul_count(const uint8_t* s, uint64_t len, int k, uint32_t parts, uint32_t* hist, uint32_t* status) {
     switch (k) {

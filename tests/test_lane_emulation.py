@@ -48,6 +48,20 @@ def emul():
                                     C.byref(st), sites) == 0
         return hist, st.value, (sites[0], sites[1])
     run.sampled = run_sampled
+
+    def run_dense(fq, k, parts):
+        """vk_count_dense_kernel's algorithm (line pass + rounds of listed granules); also returns
+        (pieces on the fast path, pieces, rounds, granules counted in rounds)."""
+        buf = np.frombuffer(bytes(fq), dtype=np.uint8) if not isinstance(fq, np.ndarray) else fq
+        pad = np.zeros(buf.size + 64, dtype=np.uint8)
+        pad[:buf.size] = buf
+        hist = np.zeros(4 ** k, dtype=np.uint32)
+        st = C.c_uint32(0)
+        stats = (C.c_uint64 * 4)()
+        L.emul_count_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.emul_count_dense(pad.ctypes.data, buf.size, k, parts, hist.ctypes.data, C.byref(st), stats) == 0
+        return hist, st.value, tuple(stats)
+    run.dense = run_dense
     return run
 
 
@@ -115,3 +129,53 @@ def test_emulated_read_subsampling_equals_oracle(emul):
                 got, status, sites = emul.sampled(fq, k, parts, seed, thr)
                 assert status == 0 and sites == wsites, (j, thr, parts, sites, wsites)
                 assert np.array_equal(got, want), (j, thr, parts)
+
+
+# ---- the sequence-only heavy stage (vk_count_dense_kernel) ------------------------------------------
+
+@pytest.mark.parametrize("k", (5, 6, 7))
+def test_dense_stage_equals_oracle_on_edge_cases(emul, k):
+    for name, fq in edge_cases().items():
+        want, nwin, st = oracle.count_fastq(fq, k)
+        for parts in (1, 3):
+            got, status, stats = emul.dense(fq, k, parts)
+            assert status == 0 and st == 0, (name, parts)
+            assert np.array_equal(got, want), (name, parts, stats)
+
+
+@pytest.mark.parametrize("dist", (0, 1))
+def test_dense_stage_equals_oracle_on_synthetic_and_takes_the_fast_path(emul, dist):
+    fq = synth.sample_fastq(21, 40000, 150, dist=dist)   # 12.8 MB: ~190 pieces per wave at parts = 1
+    for k, parts in ((5, 1), (7, 1), (7, 3), (6, 7)):
+        want = oracle.count_fastq(fq, k)[0]
+        got, status, (fast, pieces, rounds, granules) = emul.dense(fq, k, parts)
+        assert status == 0
+        assert np.array_equal(got, want), (k, parts)
+        # every piece but the first and last of a range goes through the line pass, and the rounds are full
+        assert fast >= pieces - 2 * 16 * parts, (fast, pieces)
+        assert granules > 60 * rounds
+        # sequence bytes are 151 of 320: the heavy stage sees little more than half of the granules
+        assert granules * 16 < 0.56 * len(fq), (granules * 16, len(fq))
+
+
+def test_dense_stage_fuzz(emul):
+    from fastq_cases import random_fastq, rec
+    rng = np.random.default_rng(4242)
+    blobs = [random_fastq(rng, nrec=int(rng.integers(1, 400))) for _ in range(150)]
+    # reads around the granule and block sizes, headers that end on block borders, long lines
+    for n in (13, 14, 15, 16, 17, 30, 31, 32, 33, 45, 47, 48, 49, 62, 63, 64, 65, 66, 127, 128, 129):
+        blobs.append(b"".join(rec("r%d" % i, "ACGTTGCA" * (n // 8) + "ACGTTGCA"[: n % 8]) for i in range(700)))
+        blobs.append(b"".join(rec("x" * int(rng.integers(1, 70)), "".join(rng.choice(list("ACGTN"), size=n)))
+                              for i in range(500)))
+    blobs.append(b"".join(rec("q%d" % i, "ACGT" * 3000) for i in range(12)))              # lines longer than a piece
+    blobs.append(b"".join(rec("h" * 9000, "ACGTTGCAAC" * 30) for i in range(12)))          # headers longer than a piece
+    blobs.append(b"".join(rec("u%d \xc3\xa9" % i, "ACGTTGCAAC" * 15) for i in range(300)))   # UTF-8 in the header
+    blobs.append(b"".join(rec("p%d" % i, "A" * 150) for i in range(2000)))                 # low complexity
+    for j, fq in enumerate(blobs):
+        k = 5 + j % 3
+        want, nwin, st = oracle.count_fastq(fq, k)
+        assert st == 0
+        for parts in (1, 2):
+            got, status, stats = emul.dense(fq, k, parts)
+            assert status == 0, (j, parts)
+            assert np.array_equal(got, want), (j, k, parts, len(fq), stats)

@@ -347,6 +347,51 @@ struct v_bfi_b32 {
                      : "s20", "s21", "s22", "vcc");
     }
 };
+struct v_dot4_u32_u8 {
+    static constexpr const char* name = "v_dot4_u32_u8";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_dot4_u32_u8 %0, %0, %9, %8\n\t" "v_dot4_u32_u8 %1, %1, %9, %8\n\t" "v_dot4_u32_u8 %2, %2, %9, %8\n\t" "v_dot4_u32_u8 %3, %3, %9, %8\n\t" "v_dot4_u32_u8 %4, %4, %9, %8\n\t" "v_dot4_u32_u8 %5, %5, %9, %8\n\t" "v_dot4_u32_u8 %6, %6, %9, %8\n\t" "v_dot4_u32_u8 %7, %7, %9, %8\n\t" 
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_dot4_u32_u8_acc0 {
+    static constexpr const char* name = "v_dot4_u32_u8_acc0";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_dot4_u32_u8 %0, %0, %9, 0\n\t" "v_dot4_u32_u8 %1, %1, %9, 0\n\t" "v_dot4_u32_u8 %2, %2, %9, 0\n\t" "v_dot4_u32_u8 %3, %3, %9, 0\n\t" "v_dot4_u32_u8 %4, %4, %9, 0\n\t" "v_dot4_u32_u8 %5, %5, %9, 0\n\t" "v_dot4_u32_u8 %6, %6, %9, 0\n\t" "v_dot4_u32_u8 %7, %7, %9, 0\n\t" 
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_mbcnt_lo {
+    static constexpr const char* name = "v_mbcnt_lo";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0\n\t" "v_mbcnt_lo_u32_b32 %1, -1, %1\n\t" "v_mbcnt_lo_u32_b32 %2, -1, %2\n\t" "v_mbcnt_lo_u32_b32 %3, -1, %3\n\t" "v_mbcnt_lo_u32_b32 %4, -1, %4\n\t" "v_mbcnt_lo_u32_b32 %5, -1, %5\n\t" "v_mbcnt_lo_u32_b32 %6, -1, %6\n\t" "v_mbcnt_lo_u32_b32 %7, -1, %7\n\t" 
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_cmp_e64_sgpr {
+    static constexpr const char* name = "v_cmp_e64_sgpr";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %1, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %2, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %3, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %4, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %5, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %6, %8\n\t" "v_cmp_lt_u32_e64 s[20:21], %7, %8\n\t" 
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
+struct v_cndmask_e64 {
+    static constexpr const char* name = "v_cndmask_e64";
+    __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
+        asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n\t" "v_cndmask_b32_e64 %7, %7, %8, s[20:21]\n\t" 
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "v"(b), "s"(ks)
+                     : "s20", "s21", "s22", "vcc");
+    }
+};
 struct v_add3_u32 {
     static constexpr const char* name = "v_add3_u32";
     __device__ __forceinline__ static void round(uint32_t (&a)[8], uint32_t b, uint32_t ks) {
@@ -556,6 +601,11 @@ int main() {
     run_op<v_max_u32>();
     run_op<v_bfi_b32>();
     run_op<v_add3_u32>();
+    run_op<v_dot4_u32_u8>();
+    run_op<v_dot4_u32_u8_acc0>();
+    run_op<v_mbcnt_lo>();
+    run_op<v_cmp_e64_sgpr>();
+    run_op<v_cndmask_e64>();
     run_op<v_and_then_v_perm>();
     run_op<v_and_x3_then_v_perm>();
     run_window<0>("window block (8 pos)");

@@ -27,7 +27,8 @@ for _ in range(3):
     t0 = time.perf_counter(); eng.count(fq, offs, lens, hist=hist, status=status); torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 h = hashlib.sha256(hist[:64].cpu().numpy().tobytes()).hexdigest()[:16]
-print(f"{sys.argv[1]:40s} k={k} dist={dist} pool={pool} K1 {min(ts)*1e3:8.2f} ms (min of 3; {[round(t*1e3,1) for t in ts]}) bad={int((status!=0).sum())} sha={h}", flush=True)
+import os
+print(f"{sys.argv[1] + ('@classic' if os.environ.get('VKIMG_K1_CLASSIC') == '1' else ''):40s} k={k} dist={dist} pool={pool} K1 {min(ts)*1e3:8.2f} ms (min of 3; {[round(t*1e3,1) for t in ts]}) bad={int((status!=0).sum())} sha={h}", flush=True)
 """
 
 if __name__ == "__main__":
@@ -42,7 +43,12 @@ if __name__ == "__main__":
         if a.startswith("--dist="): dist = int(a[7:])
         if a.startswith("--pool="): pool = int(a[7:])
     rc = 0
-    for lib in ["default"] + libs:
-        r = subprocess.run([sys.executable, "-c", CHILD, lib, str(k), str(samples), str(dist), str(pool)])
+    import os
+    for lib in ["default", "default@classic"] + libs:
+        env = dict(os.environ)
+        if lib.endswith("@classic"):  # the same library with VKIMG_K1_CLASSIC=1 (every byte through the heavy stage)
+            env["VKIMG_K1_CLASSIC"] = "1"
+            lib = lib[:-8]
+        r = subprocess.run([sys.executable, "-c", CHILD, lib, str(k), str(samples), str(dist), str(pool)], env=env)
         rc |= r.returncode
     sys.exit(rc)

@@ -88,5 +88,9 @@ int main() {
     run<112>(d, 1024, 67);   // K1 as shipped: one per CU expected (VGPRs)
     run<112>(d, 512, 67);
     run<128>(d, 512, 1);
+    run<64>(d, 1024, 78);    // the dense kernel's 78,912 B
+    run<64>(d, 1024, 79);
+    run<64>(d, 1024, 80);    // exactly half of the CU's 160 KB
+    run<64>(d, 896, 80);
     return 0;
 }

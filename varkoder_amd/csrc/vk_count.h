@@ -692,6 +692,417 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
     }
 }
 
+// ---- K <= 7, sequence-only heavy stage ("dense" kernel) ---------------------------------------
+// Same ranges, pieces, loads and histogram as vk_count_kernel; what changes is what a piece costs.
+// The LINE pass (vkl::newline_mask64 / seq_span, ~110 vector instructions per piece) finds each
+// lane's stretch of sequence line and lists the 16-byte granules that hold sequence bytes as u16
+// descriptors in a per-wave LDS list; the HEAVY stage then runs in rounds of 64 listed granules, one
+// per lane, re-read from L2 where the piece's loads have just put them (16-byte aligned, consecutive
+// within a read): transposes + classification + window masks + histogram updates touch sequence
+// bytes only, and a window block has ~60 live lanes instead of ~29.  Granules left over (< 64) wait
+// for the next piece.  Context (the K - 1 bases before a granule) comes from the previous lane of the
+// round -- the previous listed granule.  Where that is not the granule's neighbour in the file, its
+// last position is never a sequence base (a granule is listed as soon as ONE of its positions has
+// line phase 1, the newline that ends the line included), so no window can reach across.
+// Pieces the line pass cannot describe in this form (a lane with more than three newlines or with a
+// sequence line that starts after a '+' or quality line in the same 64 bytes: reads under ~45 bases;
+// bytes >= 0x80; low-complexity runs; the first and last piece of a range) take the general path of
+// vk_count_kernel on the registers they already hold, after the pending granules have been flushed.
+constexpr uint32_t kDescCap = 320;  // descriptors per wave: < 64 pending + 256 of one piece
+#ifndef VK_DENSE_PF
+#define VK_DENSE_PF 2                   // next piece's loads: 0 after the last round, 1 right behind the last round's own load
+#endif
+
+template <int K>
+__device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t ok, uint32_t lds_base,
+                                             uint32_t& probe_addr, unsigned long long& probe_mask) {
+    static_assert(2 * K + 2 <= 16, "paired extraction needs the field << 2 to fit 16 bits");
+    constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+    const uint32_t one = 1u;
+    uint32_t w = ok | (vkl::alignbit(ok, ok, 16u) << 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t a[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 15 - 4 * half - j;
+            const int plo = i - 8;
+            const int o = 30 + 2 * (plo - K + 1);
+            const int word = o >> 5, sh = o & 31;
+            uint32_t x;
+            if (word == 1) x = sh == 0 ? C : (C >> sh);  // the last fields end exactly at bit 64
+            else x = vkl::alignbit(C, ch, static_cast<uint32_t>(sh));
+            a[2 * j] = (x & kMask4) + lds_base;
+            a[2 * j + 1] = ((x >> 16) & kMask4) + lds_base;
+        }
+        unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+        asm volatile(
+            "v_add_co_u32_e64 %0, %1, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %2, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %3, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %4, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %5, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %6, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %7, %0, %0\n\t"
+            "v_add_co_u32_e64 %0, %8, %0, %0\n\t"
+            "s_mov_b64 exec, %1\n\tds_add_u32 %9, %17\n\t"
+            "s_mov_b64 exec, %2\n\tds_add_u32 %10, %17\n\t"
+            "s_mov_b64 exec, %3\n\tds_add_u32 %11, %17\n\t"
+            "s_mov_b64 exec, %4\n\tds_add_u32 %12, %17\n\t"
+            "s_mov_b64 exec, %5\n\tds_add_u32 %13, %17\n\t"
+            "s_mov_b64 exec, %6\n\tds_add_u32 %14, %17\n\t"
+            "s_mov_b64 exec, %7\n\tds_add_u32 %15, %17\n\t"
+            "s_mov_b64 exec, %8\n\tds_add_u32 %16, %17\n\t"
+            "s_mov_b64 exec, -1"
+            : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one)
+            : "memory");
+        if (half == 1) {
+            probe_addr = a[7];
+            probe_mask = m7;
+        }
+    }
+}
+
+// This lane's number, recomputed where it is needed (two v_mbcnt): the dense kernel's piece loop holds no
+// per-lane value across iterations besides the prefetched bytes -- what lives across the call of the
+// general path would otherwise sit in scratch and come back with a vmcnt(0) wait at every use.
+__device__ __forceinline__ uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// The general path of one piece for the dense kernel: exactly vk_count_kernel's piece (all 64 bytes of
+// every lane classified, any number of newlines, bytes >= 0x80, the low-complexity window loop).
+struct GeneralPiece {
+    uint32_t d[16];                      // this lane's 64 bytes
+    uint32_t ctx_c, ctx_bad, pph, hot;   // in / out (wave-uniform)
+    uint32_t flags, ph0;                 // bit 0: first piece of the range, bit 1: it starts with a pre-block
+};
+
+template <int K>
+__device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int lane, uint32_t* hist, uint32_t hist_base,
+                                                        const uint4* below, const uint4* above) {
+    uint32_t d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = gp->d[i];
+    auto tbl_below = [&](uint32_t q) {
+        uint4 v = below[q];
+        vkl::Mask128 m;
+        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+        return m;
+    };
+    auto tbl_above = [&](uint32_t q) {
+        uint4 v = above[q];
+        vkl::Mask128 m;
+        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+        return m;
+    };
+    const bool first = (gp->flags & 1u) != 0u, has_pre = (gp->flags & 2u) != 0u;
+    uint32_t pph = gp->pph;
+    vkl::LaneBits lb;
+    const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
+    const uint32_t incl = wave_inclusive_sum(c);
+    const uint32_t total = lane_bcast(incl, 63);
+    if (first) pph = has_pre ? gp->ph0 - lane_bcast(c, 0) : 0u;
+    const uint32_t lph = (pph + incl - c) & 3u;
+    vkl::Mask128 seq;
+    const bool degenerate = __any(c > 4u);
+    uint32_t s_raw = 0;
+    const bool four = !degenerate && __any(c > 3u);
+    if (degenerate) seq = vkl::seq_mask_general(lb.NL, lph);
+    else if (four) seq = vkl::seq_mask_fast4(lb.NL, lph, tbl_below, tbl_above, s_raw);
+    else seq = vkl::seq_mask_count(lb.NL, lph);
+    uint32_t bad[4], ok[4];
+    vkl::bad_mask(lb, seq, bad);
+    const uint32_t badh = wave_prev_lane(bad[3], gp->ctx_bad);
+    const uint32_t ch = wave_prev_lane(lb.C[3], gp->ctx_c);
+    gp->ctx_bad = lane_bcast(bad[3], 63);
+    gp->ctx_c = lane_bcast(lb.C[3], 63);
+    vkl::ok_mask<K>(badh, bad, ok);
+    if (first && lane == 0 && has_pre) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+    uint32_t pa;
+    unsigned long long pm;
+    if (gp->hot == 0u) windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
+    else windows_lds_hot<K>(ch, lb.C, ok, hist, lane, pa, pm);
+    gp->hot = probe_is_hot(pa, pm) ? 1u : 0u;
+    gp->pph = pph + total;
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+}
+
+template <int K>
+__global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kernel(
+    const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+    const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    static_assert(NCODE <= kMaxBins, "LDS histogram too large");
+    __shared__ uint32_t hist[NCODE];          // raw-field order, as in vk_count_kernel
+    __shared__ uint64_t scratch[kWaves][8];
+    __shared__ uint4 below[66];
+    __shared__ uint4 above[66];
+    __shared__ uint16_t descs[kWaves][kDescCap];
+
+    const uint32_t unit = blockIdx.x;
+    const uint32_t smp = unit / parts;
+    const uint32_t part = unit % parts;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (uint32_t i = tid; i < NCODE; i += kCountThreads) hist[i] = 0u;
+    fill_mask_tables(below, above, tid);
+    __syncthreads();
+
+    const WaveRange wr = wave_range(lens[smp], parts, part, wave);
+    uint32_t ph_start = 0, ph_end = 0;
+    if (!wr.empty) {
+        const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) uint32_t*)hist));
+        uint16_t* const dlist = &descs[wave][0];
+        const uint8_t* sbase = reinterpret_cast<const uint8_t*>(uniform64(reinterpret_cast<uint64_t>(fastq + offs[smp])));
+        const uint64_t len = uniform64(lens[smp]), w0 = uniform64(wr.w0), w1 = uniform64(wr.w1);
+        const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, &scratch[wave][0], lane) : 0u;
+        ph_start = ph0;
+        const bool has_pre = w0 != 0;
+        const uint64_t o0 = has_pre ? w0 - 64 : 0;
+        const uint64_t span = w1 - o0;
+        const uint32_t npieces = static_cast<uint32_t>((span + kPiece - 1) / kPiece);
+        const uint32_t tail_bytes = static_cast<uint32_t>(span % kPiece);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(sbase + o0), 0, static_cast<int>((span + 15) & ~15ull), 0x00020000);
+        uint4 r0, r1, r2, r3;
+        auto load_piece = [&](uint32_t piece) {
+            const uint32_t soff = piece * static_cast<uint32_t>(kPiece);
+            const uint32_t lane64 = lane_now() << 6;  // the granule offsets ride on the scalar offset
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64, soff, 0);
+            const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64, soff + 16u, 0);
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64, soff + 32u, 0);
+            const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane64, soff + 48u, 0);
+            r0 = make_uint4(a.x, a.y, a.z, a.w);
+            r1 = make_uint4(b.x, b.y, b.z, b.w);
+            r2 = make_uint4(c.x, c.y, c.z, c.w);
+            r3 = make_uint4(d.x, d.y, d.z, d.w);
+        };
+        // One dword of every 64 bytes of piece `piece`, asked for half an iteration before the piece is
+        // loaded for real: the lines wait in the XCD's L2 and the wave's wait at the top of the next
+        // iteration is an L2 hit, not a trip to HBM -- without holding the bytes in registers a whole
+        // iteration, which is what pushed their re-reads out of the L2 (VK_DENSE_PF 1, 3).
+        uint32_t touch_val = 0u, touch_sink = 0u;
+        auto touch_piece = [&](uint32_t piece) {
+            touch_val = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_now() << 6, piece * static_cast<uint32_t>(kPiece), 0);
+        };
+        auto clip_granule = [](uint4& v, int n) {
+            if (n >= 16) return;
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int kb = n - 4 * d;
+                w[d] &= kb >= 4 ? 0xFFFFFFFFu : (kb <= 0 ? 0u : ((1u << (8 * kb)) - 1u));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        };
+        // context of the next granule or block to be counted: codes and BAD of the 16 positions before it
+        uint32_t ctx_c = 0u, ctx_bad = 0x55555555u;
+        uint32_t pph = 0;       // line phase at the start of the current piece
+        uint32_t npend = 0;     // listed granules not yet counted (< 64 between pieces), dlist[0 .. npend)
+        uint32_t pend_it = 0;   // piece the oldest of them belongs to
+        bool hot = false;
+
+        // One round of the heavy stage: dlist[first .. first + n) (n <= 64; lanes beyond n idle along as
+        // granules without sequence bytes), pieces ref - 1 (parity != ref & 1) and ref.
+        // A round = 64 listed granules, dlist[first .. first + n) (n <= 64; lanes beyond n idle along as
+        // granules without sequence bytes), of the pieces ref - 1 (parity != ref & 1) and ref.
+        auto round_issue = [&](uint32_t first, uint32_t n, uint32_t ref, uint32_t& dsc, u32x4& q) __attribute__((always_inline)) {
+            dsc = vkl::kDescEndAt0;
+            const uint32_t ln = lane_now();
+            if (ln < n) dsc = dlist[first + ln];
+            const uint32_t older = ((dsc >> 8) ^ ref) & 1u;  // 1: the granule lies in piece ref - 1
+            const uint32_t voff = ((dsc & 0xFFu) << 4) + (older ? 0u : static_cast<uint32_t>(kPiece));
+            q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (ref - 1u) * static_cast<uint32_t>(kPiece), 0);
+        };
+        auto round_count = [&](uint32_t n, uint32_t dsc, const u32x4& q) __attribute__((always_inline)) {
+            uint32_t C, IV;
+            vkl::classify_granule(q.x, q.y, q.z, q.w, C, IV);
+            const uint32_t bad = (IV | ~vkl::desc_seq_mask(dsc)) & 0x55555555u;
+            const uint32_t badh = wave_prev_lane(bad, ctx_bad);
+            const uint32_t ch = wave_prev_lane(C, ctx_c);
+            ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bad), static_cast<int>(n - 1u)));
+            ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(C), static_cast<int>(n - 1u)));
+            const uint32_t ok = vkl::ok_mask1<K>(badh, bad);
+            uint32_t pa;
+            unsigned long long pm;
+            windows_lds1<K>(ch, C, ok, hist_base, pa, pm);
+            hot = probe_is_hot(pa, pm);
+        };
+        // `next` != 0: the loads of piece `next` go out right behind the round's own load (vmcnt counts in
+        // order: issued before it they would make the round wait for a whole piece from HBM).
+        auto round = [&](uint32_t first, uint32_t n, uint32_t ref, uint32_t next) __attribute__((always_inline)) {
+            uint32_t dsc;
+            u32x4 q;
+            round_issue(first, n, ref, dsc, q);
+            if (next != 0u) load_piece(next);
+            round_count(n, dsc, q);
+        };
+
+#if VK_DENSE_PF != 2 && VK_DENSE_PF != 4
+        load_piece(0);
+#endif
+        for (uint32_t it = 0; it < npieces; ++it) {
+#if VK_DENSE_PF == 2 || VK_DENSE_PF == 4
+            load_piece(it);
+#endif
+#if VK_DENSE_PF == 4
+            touch_sink ^= touch_val;  // (issued before this piece's loads: no wait of its own)
+#endif
+            if (it + 1 == npieces && (tail_bytes & 15u) != 0u) {
+                uint32_t tb = tail_bytes;
+                asm volatile("" : "+s"(tb));
+                const int n = static_cast<int>(tb) - static_cast<int>(lane_now() << 6);
+                clip_granule(r0, n);
+                clip_granule(r1, n - 16);
+                clip_granule(r2, n - 32);
+                clip_granule(r3, n - 48);
+            }
+            const uint4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;
+            const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            // ---- line pass ----
+            bool fast = it != 0 && it + 1 != npieces && !hot && !__any(vkl::ascii_or(d) != 0u);
+            uint32_t total = 0, s = 64, e = 64;
+            if (fast) {
+                uint32_t mlo, mhi;
+                vkl::newline_mask64(d, mlo, mhi);
+                const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
+                const uint32_t incl = wave_inclusive_sum(c);
+                total = lane_bcast(incl, 63);
+                const uint32_t lph = (pph + incl - c) & 3u;
+                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e);
+                const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64 gives 4 != e >> 4 or s & 15 == 0)
+                fast = !__any(!plain || both);
+            }
+            if (npend != 0u && (!fast || pend_it + 1u < it)) {  // pending granules must not fall two pieces behind
+                round(0u, npend, it - 1u, 0u);
+                npend = 0u;
+            }
+            if (fast) {
+                const uint32_t gs = s >> 4, ge = vkl::umin(e, 63u) >> 4;
+                const uint32_t n = s < 64u ? ge - gs + 1u : 0u;
+                const uint32_t incl = wave_inclusive_sum(n);
+                const uint32_t tot = npend + lane_bcast(incl, 63);
+                const uint32_t at = npend + incl - n - gs;  // + g = the granule's place in the list
+                const uint32_t ln = lane_now();
+#pragma unroll
+                for (uint32_t g = 0; g < 4; ++g)
+                    if (s < 64u && g >= gs && g <= ge)
+                        dlist[at + g] = static_cast<uint16_t>(vkl::granule_desc(ln, g, it & 1u, s, e));
+                if (npend == 0u) pend_it = it;
+                const uint32_t rounds = tot >> 6;
+#if VK_DENSE_PF == 2 || VK_DENSE_PF == 4
+                // The piece is loaded when its turn comes and its listed granules are read again within a
+                // few microseconds: an XCD's 4 MiB L2 turns over in about 7 us at this kernel's rate, and a
+                // piece prefetched one iteration ahead was gone from it by the time its rounds ran
+                // (profiles/r03a: 505 GB through the fabric per launch instead of 321).  All rounds' loads
+                // go out two rounds at a time.
+                for (uint32_t r = 0; r < rounds; r += 2u) {  // two rounds' loads in flight
+                    uint32_t da, db = vkl::kDescEndAt0;
+                    u32x4 qa, qb = {0u, 0u, 0u, 0u};
+                    const bool two = r + 1u < rounds;
+                    round_issue(r << 6, 64u, it, da, qa);
+                    if (two) round_issue((r + 1u) << 6, 64u, it, db, qb);
+#if VK_DENSE_PF == 4
+                    if (r == 0u) touch_piece(it + 1u);
+#endif
+                    round_count(64u, da, qa);
+                    if (two) round_count(64u, db, qb);
+                }
+#if VK_DENSE_PF == 4
+                if (rounds == 0u) touch_piece(it + 1u);
+#endif
+#elif VK_DENSE_PF == 3
+                {   // prefetch-ahead variant: the next piece's loads behind the last rounds' own
+                    uint32_t r = 0;
+                    for (; r + 2u < rounds; r += 2u) {
+                        uint32_t da, db;
+                        u32x4 qa, qb;
+                        round_issue(r << 6, 64u, it, da, qa);
+                        round_issue((r + 1u) << 6, 64u, it, db, qb);
+                        round_count(64u, da, qa);
+                        round_count(64u, db, qb);
+                    }
+                    uint32_t da = vkl::kDescEndAt0, db = vkl::kDescEndAt0;
+                    u32x4 qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
+                    const bool one = r < rounds, two = r + 1u < rounds;
+                    if (one) round_issue(r << 6, 64u, it, da, qa);
+                    if (two) round_issue((r + 1u) << 6, 64u, it, db, qb);
+                    load_piece(it + 1);
+                    if (one) round_count(64u, da, qa);
+                    if (two) round_count(64u, db, qb);
+                }
+#elif VK_DENSE_PF == 0
+                for (uint32_t r = 0; r < rounds; ++r) round(r << 6, 64u, it, 0u);
+                load_piece(it + 1);  // (it + 1 < npieces on this path)
+#else
+                // the last round is written out on its own: with the prefetch under a condition inside the loop
+                // the compiler no longer knows how many loads are in flight and waits for all of them
+                if (rounds != 0u) {
+                    for (uint32_t r = 0; r + 1u < rounds; ++r) round(r << 6, 64u, it, 0u);
+                    round((rounds - 1u) << 6, 64u, it, it + 1u);
+                } else {
+                    load_piece(it + 1);
+                }
+#endif
+                const uint32_t left = tot & 63u;
+                if (rounds != 0u) {
+                    const uint32_t lm = lane_now();
+                    if (left != 0u && lm < left) {
+                        const uint16_t v = dlist[(rounds << 6) + lm];
+                        dlist[lm] = v;
+                    }
+                    pend_it = it;
+                }
+                npend = left;
+                pph += total;
+                continue;
+            }
+            // ---- general path: vk_count_kernel's piece on the same bytes (a function of its own: inlined, its
+            // register needs -- all 64 bytes classified at once -- would spill the fast path's loop invariants) ----
+            GeneralPiece gp;
+            gp.ctx_c = ctx_c; gp.ctx_bad = ctx_bad; gp.pph = pph; gp.hot = hot ? 1u : 0u;
+            gp.flags = (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u);
+            gp.ph0 = ph0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gp.d[i] = d[i];
+            general_piece<K>(&gp, static_cast<int>(lane_now()), hist, hist_base, below, above);
+            ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_c)));
+            ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_bad)));
+            pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.pph)));
+            hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gp.hot)) != 0;
+#if VK_DENSE_PF != 2 && VK_DENSE_PF != 4
+            if (it + 1 < npieces) load_piece(it + 1);
+#endif
+        }
+        if (touch_sink == 0xFFFFFFFFu && wave == 99) hist[0] = 1u;  // keeps the touched dwords "used"
+        ph_end = pph & 3u;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+    }
+    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+
+    __syncthreads();
+    uint32_t* out = hist_out + static_cast<uint64_t>(smp) * NCODE;
+    for (uint32_t i = tid; i < NCODE; i += kCountThreads) {
+        const uint32_t v = hist[i];
+        const uint32_t code = pair_reverse(i, K);
+        if (atomic_flush) {
+            if (v) atomicAdd(&out[code], v);
+        } else {
+            out[code] = v;
+        }
+    }
+}
+
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
 // 4^K u32 counters do not fit LDS.  Pass A (vk_bucket_kernel) streams the FASTQ exactly like
 // vk_count_kernel, but instead of counting it PARTITIONS the windows into 16 bucket streams per

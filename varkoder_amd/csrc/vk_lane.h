@@ -462,5 +462,137 @@ VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit
     }
 }
 
+// ---- the sequence-only ("dense") stage of the K <= 7 count kernel --------------------------------
+// Header, '+' and quality lines are 53 % of a FASTQ's bytes and need nothing but their newlines found.
+// The piece loop therefore runs in two levels: a cheap LINE pass over all 64 bytes of a lane (newline
+// flags -> ordered 64-bit mask -> the lane's stretch of sequence line), which lists the 16-byte
+// GRANULES that hold sequence bytes, and the heavy stage (transposes, classification, window masks,
+// histogram updates) on listed granules only, one granule per lane, 64 granules per round.
+
+VKL_FN uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {  // sum of the four byte products + c
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    uint32_t r = c;
+    for (int i = 0; i < 4; ++i) r += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return r;
+#endif
+}
+
+VKL_FN uint32_t ascii_or(const uint32_t d[16]) {  // bit 7 of some byte set <=> the block is not all ASCII
+    uint32_t o = 0;
+    for (int i = 0; i < 16; i += 2) o |= d[i] | d[i + 1];
+    return o & 0x80808080u;
+}
+
+// Bit p of {hi, lo} set <=> byte p of the all-ASCII block is '\n'.  Per dword: the byte-wise add of
+// the ASCII classifier puts "is newline" on bit 7, one AND isolates the flags (0x80 each), and one
+// v_dot4_u32_u8 with the weights 1, 2, 4, 8 (16 .. 128 for the odd dword of a pair, accumulated)
+// lays them down in position order: 8 ordered bits per two dwords, no transposes, no shifts.
+VKL_FN void newline_mask64(const uint32_t d[16], uint32_t& lo, uint32_t& hi) {
+    uint32_t v[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t f0 = ((d[2 * k] ^ 0x75757575u) + 0x01010101u) & 0x80808080u;
+        const uint32_t f1 = ((d[2 * k + 1] ^ 0x75757575u) + 0x01010101u) & 0x80808080u;
+        v[k] = udot4(f1, 0x80402010u, udot4(f0, 0x08040201u, 0u));  // (8 ordered flags) << 7
+    }
+    lo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
+    hi = (v[4] >> 7) | (v[5] << 1) | (v[6] << 9) | (v[7] << 17);
+}
+
+VKL_FN uint32_t first_bit64(uint32_t lo, uint32_t hi) {  // index of the lowest set bit, 64 if none
+    return umin(umin(ffbl(lo), ffbl(hi) | 32u), 64u);    // 0xFFFFFFFF | 32 stays above 64
+}
+
+// The lane's stretch [s, e] of positions whose line phase is 1 (e = the newline that ends the sequence
+// line, 64 if it lies beyond the block; s = 64: none), from the newline mask, the newline count c and
+// the line phase lph at the block start.  Handles blocks with at most three newlines in which a
+// sequence line is running (lph 1) or begins after the first newline (lph 0), and blocks no sequence
+// line begins in; anything else (reads shorter than ~45 bases) returns false and the caller takes the
+// general path for the whole piece.
+VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e) {
+    const uint32_t dn = (1u - lph) & 3u;  // line ends to pass before a sequence line starts
+    const uint32_t p1 = first_bit64(lo, hi);
+    const uint32_t lo1 = lo & (lo - 1u), hi1 = lo ? hi : (hi & (hi - 1u));
+    const uint32_t p2 = first_bit64(lo1, hi1);
+    s = dn == 0u ? 0u : (dn == 1u ? umin(p1 + 1u, 64u) : 64u);
+    e = dn == 0u ? p1 : (dn == 1u ? p2 : 64u);
+    return c <= 3u && (dn <= 1u || c < dn);
+}
+
+// Granule descriptor (u16) the line pass leaves for the heavy stage:
+//   bits [0, 8)  granule of the piece (lane * 4 + g)     bit 8   parity of the piece number
+//   bit 9        0: the sequence bytes are the positions >= pos   1: the positions < pos
+//   bits [10,14) pos
+constexpr uint32_t kDescEndAt0 = 1u << 9;  // "positions < 0": no sequence byte (padding of a partial round)
+
+VKL_FN uint32_t granule_desc(uint32_t lane, uint32_t g, uint32_t parity, uint32_t s, uint32_t e) {
+    // caller guarantees the granule is live (g in [s >> 4, min(e, 63) >> 4]) and not both ends at once
+    const uint32_t base = (lane << 2) | g | (parity << 8);
+    if ((e >> 4) == g) return base | (1u << 9) | ((e & 15u) << 10);           // ends here (e < 64)
+    if ((s >> 4) == g) return base | ((s & 15u) << 10);                       // starts here (or runs through: pos 0)
+    return base;
+}
+
+VKL_FN uint32_t desc_seq_mask(uint32_t desc) {  // 2-bit geometry, both bits of a sequence position set
+    const uint32_t pos = (desc >> 10) & 15u;
+    const uint32_t below = (1u << (2u * pos)) - 1u;
+    return (desc & (1u << 9)) ? below : ~below;
+}
+
+// Heavy stage, one all-ASCII granule: codes and invalid flags in the 2-bit geometry (one dword each).
+VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout) {
+    constexpr uint32_t kLutLo = 0x41204020u, kLutHi = 0x42202053u;  // as in classify()
+    const uint32_t p01l = perm(a1, a0, 0x05010400u), p01h = perm(a1, a0, 0x07030602u);
+    const uint32_t p23l = perm(a3, a2, 0x05010400u), p23h = perm(a3, a2, 0x07030602u);
+    const uint32_t T[4] = {perm(p23l, p01l, 0x05040100u), perm(p23l, p01l, 0x07060302u),
+                           perm(p23h, p01h, 0x05040100u), perm(p23h, p01h, 0x07060302u)};
+    uint32_t C = 0, IV = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = T[j];
+        const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
+        const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
+        C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+        const uint32_t nz = x + 0x7C7C7C7Cu;
+        IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+    }
+    Cout = C;
+    IVout = IV;
+}
+
+// OK of the 16 positions of one granule (even bits) from its BAD string and the one before it.
+template <int K>
+VKL_FN uint32_t ok_mask1(uint32_t badh, uint32_t bad) {
+    uint32_t w0 = badh, w1 = bad;
+    int cover = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int step = 0; step < 4; ++step) {
+        if (cover < K) {
+            const int shp = cover < K - cover ? cover : K - cover;
+            const uint32_t sh = 2u * static_cast<uint32_t>(shp);
+            w1 |= alignbit(w1, w0, 32u - sh);
+            w0 |= w0 << sh;
+            cover += shp;
+        }
+    }
+    return ~w1 & 0x55555555u;
+}
+
+// windows() for one granule: code string [ch | C]
+template <int K, typename Emit>
+VKL_FN void windows1(uint32_t ch, uint32_t C, uint32_t ok, Emit emit) {
+    const uint64_t v = (static_cast<uint64_t>(C) << 32) | ch;
+    for (int p = 0; p < 16; ++p)
+        if ((ok >> (2 * p)) & 1u) emit(static_cast<uint32_t>((v >> (32 + 2 * (p - K + 1))) & ((1u << (2 * K)) - 1u)) << 2);
+}
+
 }  // namespace vkl
 #endif  // VK_LANE_H

@@ -88,6 +88,7 @@ struct vk_ctx {
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
+    bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
 };
 
 #define VK_HIP(ctx, call)                     \
@@ -154,9 +155,14 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     if (sub)
         hipLaunchKernelGGL((vk_count_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, *sub);
-    else
+    else if (ctx->k1_classic)
         hipLaunchKernelGGL((vk_count_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
+    else {
+        ctx->last_lds += kWaves * kDescCap * 2;
+        hipLaunchKernelGGL((vk_count_dense_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
+    }
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
 }
@@ -294,6 +300,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
+        const char* kc = getenv("VKIMG_K1_CLASSIC");
+        ctx->k1_classic = kc && kc[0] == '1';
     }
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return VK_EHIP; }
     {

@@ -178,10 +178,11 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
     return 0;
 }
 
-// csrc/vk_count.h vk_count_dense_kernel, sequentially: line pass per piece, the granule list, rounds of
-// 64 listed granules, the flush before a piece that takes the general path, context from the previous
-// listed granule.  `stats` (optional): [0] pieces on the fast path, [1] pieces in all, [2] rounds,
-// [3] granules counted in rounds.
+// csrc/vk_count.h vk_count_dense_kernel, sequentially: line pass per piece, granules with sequence bytes
+// handed through the 64-granule exchange buffer in file order (start tag on bit 7 of the first byte),
+// rounds of 64, the pending granules counted before a piece takes the general path, context from the
+// previous granule of the stream.  `stats` (optional): [0] pieces on the fast path, [1] pieces in all,
+// [2] rounds, [3] granules counted in rounds.
 template <int K>
 int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status, uint64_t* stats) {
     const uint32_t ncode = 1u << (2 * K);
@@ -200,6 +201,7 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                 break;
             }
     }
+    struct Granule { uint32_t a[4]; };
     for (uint32_t part = 0; part < parts; ++part)
         for (int wave = 0; wave < kWaves; ++wave) {
             uint64_t blk0 = (uint64_t)part * bwg + (uint64_t)wave * bw;
@@ -213,28 +215,17 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
             const uint64_t o0 = has_pre ? w0 - 64 : 0;
             const uint64_t span = w1 - o0;
             const uint32_t npieces = (uint32_t)((span + kPiece - 1) / kPiece);
-            // what the kernel's buffer descriptor returns: bytes of [o0, w1 rounded up to 16), zero beyond;
-            // bytes at or beyond w1 inside the last granule are whatever the buffer holds (here: the file's
-            // own bytes or padding) -- only the last piece clips them, and it takes the general path.
-            auto byte_at = [&](uint64_t rel) -> uint8_t {
-                const uint64_t lim = (span + 15) & ~15ull;
-                return rel < lim ? s[o0 + rel] : 0;  // s is padded by 64 readable bytes
-            };
-            uint32_t ctx_c = 0, ctx_bad = 0x55555555u, pph = 0, npend = 0, pend_it = 0;
-            std::vector<uint16_t> dlist(320, 0);
-            auto round = [&](uint32_t first, uint32_t n, uint32_t ref) {
+            uint32_t ctx_c = 0, ctx_bad = 0x55555555u, pph = 0, npend = 0;
+            Granule xb[64];
+            auto round = [&](uint32_t n) {  // xb[0 .. n) are real, lanes beyond idle along on newlines
                 uint32_t C[64], bad[64];
                 for (uint32_t lane = 0; lane < 64; ++lane) {
-                    const uint32_t dsc = lane < n ? dlist[first + lane] : vkl::kDescEndAt0;
-                    const uint32_t older = ((dsc >> 8) ^ ref) & 1u;
-                    const uint64_t rel = (uint64_t)(ref - 1u) * kPiece + ((dsc & 0xFFu) << 4) + (older ? 0u : (uint32_t)kPiece);
-                    uint32_t a[4];
-                    uint8_t b[16];
-                    for (int i = 0; i < 16; ++i) b[i] = byte_at(rel + i);
-                    memcpy(a, b, 16);
-                    uint32_t IV;
-                    vkl::classify_granule(a[0], a[1], a[2], a[3], C[lane], IV);
-                    bad[lane] = (IV | ~vkl::desc_seq_mask(dsc)) & 0x55555555u;
+                    Granule q = {{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}};
+                    if (lane < n) q = xb[lane];
+                    uint32_t IV, SEQ;
+                    vkl::classify_granule(q.a[0] & ~vkl::kGranuleStartTag, q.a[1], q.a[2], q.a[3],
+                                          (q.a[0] & vkl::kGranuleStartTag) != 0u, C[lane], IV, SEQ);
+                    bad[lane] = (IV | ~SEQ) & 0x55555555u;
                 }
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     const uint32_t badh = lane ? bad[lane - 1] : ctx_bad, ch = lane ? C[lane - 1] : ctx_c;
@@ -271,39 +262,36 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
                         const uint32_t lph = (pph + excl) & 3u;
                         excl += c;
-                        const bool plain = vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane]);
-                        const bool both = (sp[lane] >> 4) == (ep[lane] >> 4) && (sp[lane] & 15u) != 0u;
-                        if (!plain || both) all_plain = false;
+                        if (!vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane])) all_plain = false;
                     }
                     total = excl;
                     fast = all_plain;
                 }
-                if (npend != 0 && (!fast || pend_it + 1 < it)) {
-                    round(0, npend, it - 1);
-                    npend = 0;
-                }
                 if (fast) {
                     if (stats) stats[0]++;
-                    if (npend == 0) pend_it = it;
-                    uint32_t at = npend;
+                    // the stream of this piece's granules, behind the pending ones; 64 at a time
                     for (uint32_t lane = 0; lane < 64; ++lane) {
                         const uint32_t sl = sp[lane], el = ep[lane];
-                        if (sl >= 64) continue;
-                        const uint32_t gs = sl >> 4, ge = std::min(el, 63u) >> 4;
-                        for (uint32_t g = gs; g <= ge; ++g) dlist[at++] = (uint16_t)vkl::granule_desc(lane, g, it & 1u, sl, el);
+                        const uint32_t gs = vkl::span_first(sl), n = vkl::span_count(sl, el);
+                        for (uint32_t g = gs; g < gs + n; ++g) {
+                            Granule q;
+                            memcpy(q.a, piece + 64 * lane + 16 * g, 16);
+                            if (g == gs && vkl::span_starts_inside(sl)) q.a[0] |= vkl::kGranuleStartTag;
+                            xb[npend++] = q;
+                            if (npend == 64) {
+                                round(64);
+                                npend = 0;
+                            }
+                        }
                     }
-                    const uint32_t tot = at, rounds = tot >> 6;
-                    for (uint32_t r = 0; r < rounds; ++r) round(r << 6, 64, it);
-                    const uint32_t left = tot & 63u;
-                    if (rounds) {
-                        for (uint32_t j = 0; j < left; ++j) dlist[j] = dlist[(rounds << 6) + j];
-                        pend_it = it;
-                    }
-                    npend = left;
                     pph += total;
                     continue;
                 }
                 // general path
+                if (npend != 0) {
+                    round(npend);
+                    npend = 0;
+                }
                 vkl::LaneBits lb[64];
                 uint32_t c[64];
                 bool non_ascii = false;

@@ -313,3 +313,40 @@ def test_large_image_order_statistics_by_counting(engines, k, mapping):
     for i, name in enumerate(names):
         want = oracle.image(oracle.strand_merge(fwd[i], k), k, lut, s * s)
         assert np.array_equal(img[i].ravel(), want), name
+
+
+# ---- the sequence-only heavy stage of the k <= 7 kernel (vk_count_dense_kernel) --------------------
+
+import functools
+
+
+@functools.lru_cache(maxsize=1)
+def _dense_blobs():
+    """Inputs large enough to leave the first / last piece of a wave's range (those take the general
+    path): reads around the granule (16 B) and block (64 B) sizes, ragged reads, headers that end on
+    block borders, very long lines, bytes >= 0x80 in headers, low complexity, CRLF, odd alphabets."""
+    from fastq_cases import random_fastq, rec
+    rng = np.random.default_rng(31337)
+    blobs = [random_fastq(rng, nrec=int(rng.integers(1500, 6000))) for _ in range(10)]
+    for n in (14, 15, 16, 17, 31, 33, 45, 47, 48, 49, 63, 64, 65, 129, 150, 151, 250):
+        blobs.append(b"".join(rec("x" * int(rng.integers(1, 70)), "".join(rng.choice(list("ACGTN"), size=n)))
+                              for _ in range(6000)))
+    blobs.append(b"".join(rec("q%d" % i, "ACGT" * 3000) for i in range(120)))
+    blobs.append(b"".join(rec("h" * 9000, "ACGTTGCAAC" * 30) for i in range(120)))
+    blobs.append(b"".join(rec("u%d \xc3\xa9" % i, "ACGTTGCAAC" * 15) for i in range(6000)))
+    blobs.append(b"".join(rec("p%d" % i, "A" * 150 if i % 3 else "ACGTTGCAAC" * 15) for i in range(8000)))
+    return blobs
+
+
+@pytest.mark.parametrize("k", (5, 6, 7))
+def test_dense_stage_matches_oracle_and_classic_kernel(engines, k):
+    eng = engines(k)
+    blobs = _dense_blobs()
+    dev, offs, lens = eng.upload(blobs)
+    want = np.stack([oracle.count_fastq(b, k)[0] for b in blobs])
+    for parts in (0, 1, 2, 5):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any(), parts
+        got = hist.cpu().numpy().view(np.uint32)
+        bad = [i for i in range(len(blobs)) if not np.array_equal(got[i], want[i])]
+        assert not bad, (k, parts, bad)

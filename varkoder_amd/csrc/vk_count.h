@@ -694,24 +694,25 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
 
 // ---- K <= 7, sequence-only heavy stage ("dense" kernel) ---------------------------------------
 // Same ranges, pieces, loads and histogram as vk_count_kernel; what changes is what a piece costs.
-// The LINE pass (vkl::newline_mask64 / seq_span, ~110 vector instructions per piece) finds each
-// lane's stretch of sequence line and lists the 16-byte granules that hold sequence bytes as u16
-// descriptors in a per-wave LDS list; the HEAVY stage then runs in rounds of 64 listed granules, one
-// per lane, re-read from L2 where the piece's loads have just put them (16-byte aligned, consecutive
-// within a read): transposes + classification + window masks + histogram updates touch sequence
-// bytes only, and a window block has ~60 live lanes instead of ~29.  Granules left over (< 64) wait
-// for the next piece.  Context (the K - 1 bases before a granule) comes from the previous lane of the
-// round -- the previous listed granule.  Where that is not the granule's neighbour in the file, its
-// last position is never a sequence base (a granule is listed as soon as ONE of its positions has
-// line phase 1, the newline that ends the line included), so no window can reach across.
+// The LINE pass (vkl::newline_mask64 / seq_span, ~130 vector instructions per piece, no transposes)
+// finds each lane's stretch of sequence line; the 16-byte granules that hold sequence bytes (52 % of
+// all granules for 150-base reads) are handed from the registers of the lanes that loaded them to the
+// lanes of the HEAVY stage through a 1 KiB exchange buffer per wave in LDS: 64 granules = one round,
+// one granule per lane, in file order.  Transposes, classification, window masks and histogram updates
+// then touch sequence bytes only, and a window block has ~60 live lanes instead of ~29.  Granules left
+// over (< 64) stay in the buffer for the next piece.  Context (the K - 1 bases before a granule) comes
+// from the previous lane of the round -- the previous granule of the stream.  Where that is not the
+// granule's neighbour in the file, its last position is never a sequence base (a granule goes to the
+// heavy stage as soon as ONE of its positions has line phase 1, the newline that ends the line
+// included), so no window can reach across.  What a granule's sequence bytes are needs one bit of
+// company: "the line starts inside" (bit 7 of the first byte; the bytes are ASCII) -- otherwise they are
+// the bytes before its first newline.
 // Pieces the line pass cannot describe in this form (a lane with more than three newlines or with a
 // sequence line that starts after a '+' or quality line in the same 64 bytes: reads under ~45 bases;
 // bytes >= 0x80; low-complexity runs; the first and last piece of a range) take the general path of
-// vk_count_kernel on the registers they already hold, after the pending granules have been flushed.
-constexpr uint32_t kDescCap = 320;  // descriptors per wave: < 64 pending + 256 of one piece
-#ifndef VK_DENSE_PF
-#define VK_DENSE_PF 2                   // next piece's loads: 0 after the last round, 1 right behind the last round's own load
-#endif
+// vk_count_kernel on the registers they already hold, after the pending granules have been counted.
+// LDS: 64 KiB histogram + 16 x 1 KiB exchange = exactly half of a CU's 160 KiB, two workgroups per CU
+// (tools/occupancy_census.hip: they do co-reside); the range-start scratch lives in the wave's buffer.
 
 template <int K>
 __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t ok, uint32_t lds_base,
@@ -774,7 +775,8 @@ __device__ __forceinline__ uint32_t lane_now() {
 }
 
 // The general path of one piece for the dense kernel: exactly vk_count_kernel's piece (all 64 bytes of
-// every lane classified, any number of newlines, bytes >= 0x80, the low-complexity window loop).
+// every lane classified, any number of newlines, bytes >= 0x80, the low-complexity window loop); the
+// mask tables of the rare tiers are worked out on the spot (no LDS left for them).
 struct GeneralPiece {
     uint32_t d[16];                      // this lane's 64 bytes
     uint32_t ctx_c, ctx_bad, pph, hot;   // in / out (wave-uniform)
@@ -782,23 +784,10 @@ struct GeneralPiece {
 };
 
 template <int K>
-__device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int lane, uint32_t* hist, uint32_t hist_base,
-                                                        const uint4* below, const uint4* above) {
+__device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int lane, uint32_t* hist, uint32_t hist_base) {
     uint32_t d[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = gp->d[i];
-    auto tbl_below = [&](uint32_t q) {
-        uint4 v = below[q];
-        vkl::Mask128 m;
-        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
-        return m;
-    };
-    auto tbl_above = [&](uint32_t q) {
-        uint4 v = above[q];
-        vkl::Mask128 m;
-        m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
-        return m;
-    };
     const bool first = (gp->flags & 1u) != 0u, has_pre = (gp->flags & 2u) != 0u;
     uint32_t pph = gp->pph;
     vkl::LaneBits lb;
@@ -812,7 +801,7 @@ __device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int la
     uint32_t s_raw = 0;
     const bool four = !degenerate && __any(c > 3u);
     if (degenerate) seq = vkl::seq_mask_general(lb.NL, lph);
-    else if (four) seq = vkl::seq_mask_fast4(lb.NL, lph, tbl_below, tbl_above, s_raw);
+    else if (four) seq = vkl::seq_mask_fast4(lb.NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
     else seq = vkl::seq_mask_count(lb.NL, lph);
     uint32_t bad[4], ok[4];
     vkl::bad_mask(lb, seq, bad);
@@ -838,11 +827,8 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
     constexpr uint32_t NCODE = 1u << (2 * K);
     static_assert(NCODE <= kMaxBins, "LDS histogram too large");
-    __shared__ uint32_t hist[NCODE];          // raw-field order, as in vk_count_kernel
-    __shared__ uint64_t scratch[kWaves][8];
-    __shared__ uint4 below[66];
-    __shared__ uint4 above[66];
-    __shared__ uint16_t descs[kWaves][kDescCap];
+    __shared__ uint32_t hist[NCODE];       // raw-field order, as in vk_count_kernel
+    __shared__ uint4 xbuf[kWaves][64];     // per wave: 64 granules on their way to the heavy stage
 
     const uint32_t unit = blockIdx.x;
     const uint32_t smp = unit / parts;
@@ -852,7 +838,6 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (uint32_t i = tid; i < NCODE; i += kCountThreads) hist[i] = 0u;
-    fill_mask_tables(below, above, tid);
     __syncthreads();
 
     const WaveRange wr = wave_range(lens[smp], parts, part, wave);
@@ -860,10 +845,10 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
-        uint16_t* const dlist = &descs[wave][0];
+        uint4* const xb = &xbuf[wave][0];
         const uint8_t* sbase = reinterpret_cast<const uint8_t*>(uniform64(reinterpret_cast<uint64_t>(fastq + offs[smp])));
         const uint64_t len = uniform64(lens[smp]), w0 = uniform64(wr.w0), w1 = uniform64(wr.w1);
-        const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, &scratch[wave][0], lane) : 0u;
+        const uint32_t ph0 = (w0 != 0) ? sync_phase(sbase, w0, len, reinterpret_cast<uint64_t*>(xb), lane) : 0u;
         ph_start = ph0;
         const bool has_pre = w0 != 0;
         const uint64_t o0 = has_pre ? w0 - 64 : 0;
@@ -886,14 +871,6 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             r2 = make_uint4(c.x, c.y, c.z, c.w);
             r3 = make_uint4(d.x, d.y, d.z, d.w);
         };
-        // One dword of every 64 bytes of piece `piece`, asked for half an iteration before the piece is
-        // loaded for real: the lines wait in the XCD's L2 and the wave's wait at the top of the next
-        // iteration is an L2 hit, not a trip to HBM -- without holding the bytes in registers a whole
-        // iteration, which is what pushed their re-reads out of the L2 (VK_DENSE_PF 1, 3).
-        uint32_t touch_val = 0u, touch_sink = 0u;
-        auto touch_piece = [&](uint32_t piece) {
-            touch_val = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_now() << 6, piece * static_cast<uint32_t>(kPiece), 0);
-        };
         auto clip_granule = [](uint4& v, int n) {
             if (n >= 16) return;
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -904,29 +881,19 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             }
             v = make_uint4(w[0], w[1], w[2], w[3]);
         };
+
         // context of the next granule or block to be counted: codes and BAD of the 16 positions before it
         uint32_t ctx_c = 0u, ctx_bad = 0x55555555u;
-        uint32_t pph = 0;       // line phase at the start of the current piece
-        uint32_t npend = 0;     // listed granules not yet counted (< 64 between pieces), dlist[0 .. npend)
-        uint32_t pend_it = 0;   // piece the oldest of them belongs to
+        uint32_t pph = 0;     // line phase at the start of the current piece
+        uint32_t npend = 0;   // granules waiting in xb[0 .. npend), < 64 between pieces
         bool hot = false;
 
-        // One round of the heavy stage: dlist[first .. first + n) (n <= 64; lanes beyond n idle along as
-        // granules without sequence bytes), pieces ref - 1 (parity != ref & 1) and ref.
-        // A round = 64 listed granules, dlist[first .. first + n) (n <= 64; lanes beyond n idle along as
-        // granules without sequence bytes), of the pieces ref - 1 (parity != ref & 1) and ref.
-        auto round_issue = [&](uint32_t first, uint32_t n, uint32_t ref, uint32_t& dsc, u32x4& q) __attribute__((always_inline)) {
-            dsc = vkl::kDescEndAt0;
-            const uint32_t ln = lane_now();
-            if (ln < n) dsc = dlist[first + ln];
-            const uint32_t older = ((dsc >> 8) ^ ref) & 1u;  // 1: the granule lies in piece ref - 1
-            const uint32_t voff = ((dsc & 0xFFu) << 4) + (older ? 0u : static_cast<uint32_t>(kPiece));
-            q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (ref - 1u) * static_cast<uint32_t>(kPiece), 0);
-        };
-        auto round_count = [&](uint32_t n, uint32_t dsc, const u32x4& q) __attribute__((always_inline)) {
-            uint32_t C, IV;
-            vkl::classify_granule(q.x, q.y, q.z, q.w, C, IV);
-            const uint32_t bad = (IV | ~vkl::desc_seq_mask(dsc)) & 0x55555555u;
+        // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
+        // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
+        auto round_count = [&](uint32_t n, uint4 q, bool probe) __attribute__((always_inline)) {
+            uint32_t C, IV, SEQ;
+            vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
+            const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
             const uint32_t badh = wave_prev_lane(bad, ctx_bad);
             const uint32_t ch = wave_prev_lane(C, ctx_c);
             ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bad), static_cast<int>(n - 1u)));
@@ -935,28 +902,18 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             uint32_t pa;
             unsigned long long pm;
             windows_lds1<K>(ch, C, ok, hist_base, pa, pm);
-            hot = probe_is_hot(pa, pm);
+            if (probe) hot = probe_is_hot(pa, pm);
         };
-        // `next` != 0: the loads of piece `next` go out right behind the round's own load (vmcnt counts in
-        // order: issued before it they would make the round wait for a whole piece from HBM).
-        auto round = [&](uint32_t first, uint32_t n, uint32_t ref, uint32_t next) __attribute__((always_inline)) {
-            uint32_t dsc;
-            u32x4 q;
-            round_issue(first, n, ref, dsc, q);
-            if (next != 0u) load_piece(next);
-            round_count(n, dsc, q);
+        auto flush = [&]() __attribute__((always_inline)) {  // the pending granules, before a piece takes the general path
+            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            const uint32_t ln = lane_now();
+            if (ln < npend) q = xb[ln];
+            round_count(npend, q, true);
+            npend = 0u;
         };
 
-#if VK_DENSE_PF != 2 && VK_DENSE_PF != 4
         load_piece(0);
-#endif
         for (uint32_t it = 0; it < npieces; ++it) {
-#if VK_DENSE_PF == 2 || VK_DENSE_PF == 4
-            load_piece(it);
-#endif
-#if VK_DENSE_PF == 4
-            touch_sink ^= touch_val;  // (issued before this piece's loads: no wait of its own)
-#endif
             if (it + 1 == npieces && (tail_bytes & 15u) != 0u) {
                 uint32_t tb = tail_bytes;
                 asm volatile("" : "+s"(tb));
@@ -979,112 +936,64 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 const uint32_t incl = wave_inclusive_sum(c);
                 total = lane_bcast(incl, 63);
                 const uint32_t lph = (pph + incl - c) & 3u;
-                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e);
-                const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64 gives 4 != e >> 4 or s & 15 == 0)
-                fast = !__any(!plain || both);
+                fast = !__any(!vkl::seq_span(mlo, mhi, c, lph, s, e));
             }
-            if (npend != 0u && (!fast || pend_it + 1u < it)) {  // pending granules must not fall two pieces behind
-                round(0u, npend, it - 1u, 0u);
-                npend = 0u;
-            }
-            if (fast) {
-                const uint32_t gs = s >> 4, ge = vkl::umin(e, 63u) >> 4;
-                const uint32_t n = s < 64u ? ge - gs + 1u : 0u;
-                const uint32_t incl = wave_inclusive_sum(n);
-                const uint32_t tot = npend + lane_bcast(incl, 63);
-                const uint32_t at = npend + incl - n - gs;  // + g = the granule's place in the list
-                const uint32_t ln = lane_now();
+            if (!fast) {
+                // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
+                // classified at once -- would spill the fast path's loop invariants) ----
+                if (npend != 0u) flush();
+                GeneralPiece gp;
+                gp.ctx_c = ctx_c; gp.ctx_bad = ctx_bad; gp.pph = pph; gp.hot = hot ? 1u : 0u;
+                gp.flags = (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u);
+                gp.ph0 = ph0;
 #pragma unroll
-                for (uint32_t g = 0; g < 4; ++g)
-                    if (s < 64u && g >= gs && g <= ge)
-                        dlist[at + g] = static_cast<uint16_t>(vkl::granule_desc(ln, g, it & 1u, s, e));
-                if (npend == 0u) pend_it = it;
-                const uint32_t rounds = tot >> 6;
-#if VK_DENSE_PF == 2 || VK_DENSE_PF == 4
-                // The piece is loaded when its turn comes and its listed granules are read again within a
-                // few microseconds: an XCD's 4 MiB L2 turns over in about 7 us at this kernel's rate, and a
-                // piece prefetched one iteration ahead was gone from it by the time its rounds ran
-                // (profiles/r03a: 505 GB through the fabric per launch instead of 321).  All rounds' loads
-                // go out two rounds at a time.
-                for (uint32_t r = 0; r < rounds; r += 2u) {  // two rounds' loads in flight
-                    uint32_t da, db = vkl::kDescEndAt0;
-                    u32x4 qa, qb = {0u, 0u, 0u, 0u};
-                    const bool two = r + 1u < rounds;
-                    round_issue(r << 6, 64u, it, da, qa);
-                    if (two) round_issue((r + 1u) << 6, 64u, it, db, qb);
-#if VK_DENSE_PF == 4
-                    if (r == 0u) touch_piece(it + 1u);
-#endif
-                    round_count(64u, da, qa);
-                    if (two) round_count(64u, db, qb);
-                }
-#if VK_DENSE_PF == 4
-                if (rounds == 0u) touch_piece(it + 1u);
-#endif
-#elif VK_DENSE_PF == 3
-                {   // prefetch-ahead variant: the next piece's loads behind the last rounds' own
-                    uint32_t r = 0;
-                    for (; r + 2u < rounds; r += 2u) {
-                        uint32_t da, db;
-                        u32x4 qa, qb;
-                        round_issue(r << 6, 64u, it, da, qa);
-                        round_issue((r + 1u) << 6, 64u, it, db, qb);
-                        round_count(64u, da, qa);
-                        round_count(64u, db, qb);
-                    }
-                    uint32_t da = vkl::kDescEndAt0, db = vkl::kDescEndAt0;
-                    u32x4 qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
-                    const bool one = r < rounds, two = r + 1u < rounds;
-                    if (one) round_issue(r << 6, 64u, it, da, qa);
-                    if (two) round_issue((r + 1u) << 6, 64u, it, db, qb);
-                    load_piece(it + 1);
-                    if (one) round_count(64u, da, qa);
-                    if (two) round_count(64u, db, qb);
-                }
-#elif VK_DENSE_PF == 0
-                for (uint32_t r = 0; r < rounds; ++r) round(r << 6, 64u, it, 0u);
-                load_piece(it + 1);  // (it + 1 < npieces on this path)
-#else
-                // the last round is written out on its own: with the prefetch under a condition inside the loop
-                // the compiler no longer knows how many loads are in flight and waits for all of them
-                if (rounds != 0u) {
-                    for (uint32_t r = 0; r + 1u < rounds; ++r) round(r << 6, 64u, it, 0u);
-                    round((rounds - 1u) << 6, 64u, it, it + 1u);
-                } else {
-                    load_piece(it + 1);
-                }
-#endif
-                const uint32_t left = tot & 63u;
-                if (rounds != 0u) {
-                    const uint32_t lm = lane_now();
-                    if (left != 0u && lm < left) {
-                        const uint16_t v = dlist[(rounds << 6) + lm];
-                        dlist[lm] = v;
-                    }
-                    pend_it = it;
-                }
-                npend = left;
-                pph += total;
+                for (int i = 0; i < 16; ++i) gp.d[i] = d[i];
+                general_piece<K>(&gp, static_cast<int>(lane_now()), hist, hist_base);
+                ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_c)));
+                ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_bad)));
+                pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.pph)));
+                hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gp.hot)) != 0;
+                if (it + 1 < npieces) load_piece(it + 1);
                 continue;
             }
-            // ---- general path: vk_count_kernel's piece on the same bytes (a function of its own: inlined, its
-            // register needs -- all 64 bytes classified at once -- would spill the fast path's loop invariants) ----
-            GeneralPiece gp;
-            gp.ctx_c = ctx_c; gp.ctx_bad = ctx_bad; gp.pph = pph; gp.hot = hot ? 1u : 0u;
-            gp.flags = (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u);
-            gp.ph0 = ph0;
+            // ---- hand the granules with sequence bytes to the heavy stage, 64 at a time ----
+            const uint32_t gs = vkl::span_first(s), n = vkl::span_count(s, e);
+            const uint32_t incl = wave_inclusive_sum(n);
+            const uint32_t tot = npend + lane_bcast(incl, 63);
+            const uint32_t first = npend + incl - n - gs;  // + g = the granule's place in the stream (64 per round)
+            // place and round of every granule of this lane (0xFFFF....: none of its rounds)
+            uint32_t wp[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gp.d[i] = d[i];
-            general_piece<K>(&gp, static_cast<int>(lane_now()), hist, hist_base, below, above);
-            ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_c)));
-            ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_bad)));
-            pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.pph)));
-            hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gp.hot)) != 0;
-#if VK_DENSE_PF != 2 && VK_DENSE_PF != 4
-            if (it + 1 < npieces) load_piece(it + 1);
-#endif
+            for (uint32_t g = 0; g < 4; ++g) wp[g] = (g - gs < n) ? first + g : 0xFFFFFFC0u;
+            // the start tag is set on the granule's copy in the buffer (the piece's registers stay as loaded:
+            // four aligned 128-bit tuples the stores can take as they are)
+            const uint32_t wtag = vkl::span_starts_inside(s) ? first + gs : 0xFFFFFFC0u;
+            const uint32_t rounds = tot >> 6;
+            auto put = [&](uint32_t r) __attribute__((always_inline)) {  // the granules whose round is r
+                if ((wp[0] >> 6) == r) xb[wp[0] & 63u] = r0;
+                if ((wp[1] >> 6) == r) xb[wp[1] & 63u] = r1;
+                if ((wp[2] >> 6) == r) xb[wp[2] & 63u] = r2;
+                if ((wp[3] >> 6) == r) xb[wp[3] & 63u] = r3;
+                if ((wtag >> 6) == r) atomicOr(&xb[wtag & 63u].x, vkl::kGranuleStartTag);
+            };
+            if (rounds != 0u) {
+                for (uint32_t r = 0; r + 1u < rounds; ++r) {
+                    put(r);
+                    const uint4 q = xb[lane_now()];
+                    round_count(64u, q, false);
+                }
+                put(rounds - 1u);
+                const uint4 q = xb[lane_now()];
+                put(rounds);          // what is left stays in the buffer for the next piece
+                load_piece(it + 1);   // (it + 1 < npieces on this path) -- under the last round's arithmetic
+                round_count(64u, q, true);
+            } else {
+                put(0u);
+                load_piece(it + 1);
+            }
+            npend = tot & 63u;
+            pph += total;
         }
-        if (touch_sink == 0xFFFFFFFFu && wave == 99) hist[0] = 1u;  // keeps the touched dwords "used"
         ph_end = pph & 3u;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
     }

@@ -465,9 +465,9 @@ VKL_FN void windows(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], Emit
 // ---- the sequence-only ("dense") stage of the K <= 7 count kernel --------------------------------
 // Header, '+' and quality lines are 53 % of a FASTQ's bytes and need nothing but their newlines found.
 // The piece loop therefore runs in two levels: a cheap LINE pass over all 64 bytes of a lane (newline
-// flags -> ordered 64-bit mask -> the lane's stretch of sequence line), which lists the 16-byte
+// flags -> ordered 64-bit mask -> the lane's stretch of sequence line), which picks the 16-byte
 // GRANULES that hold sequence bytes, and the heavy stage (transposes, classification, window masks,
-// histogram updates) on listed granules only, one granule per lane, 64 granules per round.
+// histogram updates) on those granules only, one granule per lane, 64 granules per round.
 
 VKL_FN uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) {  // sum of the four byte products + c
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -512,7 +512,8 @@ VKL_FN uint32_t first_bit64(uint32_t lo, uint32_t hi) {  // index of the lowest 
 // the line phase lph at the block start.  Handles blocks with at most three newlines in which a
 // sequence line is running (lph 1) or begins after the first newline (lph 0), and blocks no sequence
 // line begins in; anything else (reads shorter than ~45 bases) returns false and the caller takes the
-// general path for the whole piece.
+// general path for the whole piece.  A granule (16 positions) that holds both the start of a sequence
+// line (not at its first position) and the end of that line is refused too (reads under 15 bases).
 VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e) {
     const uint32_t dn = (1u - lph) & 3u;  // line ends to pass before a sequence line starts
     const uint32_t p1 = first_bit64(lo, hi);
@@ -520,37 +521,33 @@ VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_
     const uint32_t p2 = first_bit64(lo1, hi1);
     s = dn == 0u ? 0u : (dn == 1u ? umin(p1 + 1u, 64u) : 64u);
     e = dn == 0u ? p1 : (dn == 1u ? p2 : 64u);
-    return c <= 3u && (dn <= 1u || c < dn);
+    const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64: s & 15 == 0)
+    return c <= 3u && (dn <= 1u || c < dn) && !both;
 }
 
-// Granule descriptor (u16) the line pass leaves for the heavy stage:
-//   bits [0, 8)  granule of the piece (lane * 4 + g)     bit 8   parity of the piece number
-//   bit 9        0: the sequence bytes are the positions >= pos   1: the positions < pos
-//   bits [10,14) pos
-constexpr uint32_t kDescEndAt0 = 1u << 9;  // "positions < 0": no sequence byte (padding of a partial round)
+// The granules of a lane that go to the heavy stage: every granule with a position of line phase 1,
+// the newline that ends the line included -- so that where two granules follow each other in the
+// heavy stage without being neighbours in the file, the first one's last position is never a base.
+VKL_FN uint32_t span_first(uint32_t s) { return s >> 4; }
+VKL_FN uint32_t span_last(uint32_t e) { return umin(e, 63u) >> 4; }
+VKL_FN uint32_t span_count(uint32_t s, uint32_t e) { return s < 64u ? span_last(e) - span_first(s) + 1u : 0u; }
 
-VKL_FN uint32_t granule_desc(uint32_t lane, uint32_t g, uint32_t parity, uint32_t s, uint32_t e) {
-    // caller guarantees the granule is live (g in [s >> 4, min(e, 63) >> 4]) and not both ends at once
-    const uint32_t base = (lane << 2) | g | (parity << 8);
-    if ((e >> 4) == g) return base | (1u << 9) | ((e & 15u) << 10);           // ends here (e < 64)
-    if ((s >> 4) == g) return base | ((s & 15u) << 10);                       // starts here (or runs through: pos 0)
-    return base;
-}
+// A granule whose sequence line STARTS inside it (after the newline of a header line) travels with bit 7
+// of its first byte set (the bytes are ASCII); every other granule's sequence bytes are those before
+// its first newline, or all of them.
+constexpr uint32_t kGranuleStartTag = 0x80u;
+VKL_FN bool span_starts_inside(uint32_t s) { return s < 64u && (s & 15u) != 0u; }
 
-VKL_FN uint32_t desc_seq_mask(uint32_t desc) {  // 2-bit geometry, both bits of a sequence position set
-    const uint32_t pos = (desc >> 10) & 15u;
-    const uint32_t below = (1u << (2u * pos)) - 1u;
-    return (desc & (1u << 9)) ? below : ~below;
-}
-
-// Heavy stage, one all-ASCII granule: codes and invalid flags in the 2-bit geometry (one dword each).
-VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout) {
+// Heavy stage, one all-ASCII granule (start tag already taken off): codes, invalid flags and the
+// sequence-byte mask in the 2-bit geometry (one dword each; SEQ on both bits of a position).
+VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, bool starts_inside,
+                             uint32_t& Cout, uint32_t& IVout, uint32_t& SEQout) {
     constexpr uint32_t kLutLo = 0x41204020u, kLutHi = 0x42202053u;  // as in classify()
     const uint32_t p01l = perm(a1, a0, 0x05010400u), p01h = perm(a1, a0, 0x07030602u);
     const uint32_t p23l = perm(a3, a2, 0x05010400u), p23h = perm(a3, a2, 0x07030602u);
     const uint32_t T[4] = {perm(p23l, p01l, 0x05040100u), perm(p23l, p01l, 0x07060302u),
                            perm(p23h, p01h, 0x05040100u), perm(p23h, p01h, 0x07060302u)};
-    uint32_t C = 0, IV = 0;
+    uint32_t C = 0, IV = 0, NL = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -560,10 +557,14 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
         const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
         C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
         const uint32_t nz = x + 0x7C7C7C7Cu;
+        const uint32_t eq = xor_add_k(t, 0x75757575u, 0x01010101u);
         IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+        NL = and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
     }
+    const uint32_t low = (NL - 1u) & ~NL;  // everything below the first newline (all ones without one)
     Cout = C;
     IVout = IV;
+    SEQout = starts_inside ? ~((low << 2) | 3u) : low;
 }
 
 // OK of the 16 positions of one granule (even bits) from its BAD string and the one before it.

@@ -159,7 +159,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         hipLaunchKernelGGL((vk_count_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
     else {
-        ctx->last_lds += kWaves * kDescCap * 2;
+        ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * 1024;
         hipLaunchKernelGGL((vk_count_dense_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
     }

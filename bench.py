@@ -7,9 +7,14 @@ k=7 varKode (91x91), 1x MI355X.  One "step" = one pass of the whole hot path
 (FASTQ text resident in HBM -> k-mer histograms -> uint8 images) over that batch.
 
 320 GB of distinct text does not fit one GPU, so -- as SURVEY.md 8d prescribes -- a pool
-of `--pool` distinct samples (default 256 = 82 GB, one per concurrently resident workgroup) is generated on the device and the
-batch of 1000 cycles through it; every batch entry still gets its own histogram and
+of `--pool` distinct samples (default 512 = 164 GB: one per workgroup the 256 CUs keep resident, two
+per CU, so that no two workgroups running at the same time read the same bytes) is generated on the
+device and the batch of 1000 cycles through it; every batch entry still gets its own histogram and
 image.  Generation is outside the timed region.
+
+Side legs at N=1, each in the same JSON line and none of them `value`: `config4` (BASELINE.json
+configs[3]: k=9 cgr, 100 samples, both base distributions -- the LDS-spill path), `cpu_baseline`,
+`end_to_end` (files on disk -> PNG files).
 
 N>1 = BASELINE.json configs[2]: 10000 samples sharded over the N GPUs (ceil(10000/N) per rank per
 step, no data-path collective: samples are independent, as in the reference's sample-level pool,
@@ -46,13 +51,18 @@ def parse():
     ap.add_argument("--readlen", type=int, default=150)
     ap.add_argument("--k", type=int, default=7)
     ap.add_argument("--mapping", default="varKode")
-    ap.add_argument("--pool", type=int, default=256, help="distinct samples resident in HBM")
+    ap.add_argument("--pool", type=int, default=512, help="distinct samples resident in HBM (512 = one per resident workgroup)")
     ap.add_argument("--dist", type=int, default=0, help="0 uniform, 1 GC-skew + homopolymers")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per sample (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files -> PNGs measurement (N=1 only)")
-    ap.add_argument("--e2e-files", type=int, default=64)
-    ap.add_argument("--e2e-reads", type=int, default=400_000, help="reads per file of the end-to-end measurement")
+    ap.add_argument("--no-config4", action="store_true", help="skip the k=9 side leg (N=1 only)")
+    ap.add_argument("--config4-samples", type=int, default=100)
+    ap.add_argument("--config4-steps", type=int, default=5)
+    ap.add_argument("--e2e-files", type=int, default=256)
+    ap.add_argument("--e2e-reads", type=int, default=560_000, help="reads per file of the end-to-end measurement "
+                    "(256 x 560k x 150 bp = 21.5 Gbases: about a second per pass)")
+    ap.add_argument("--e2e-passes", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this "
                     "process may use: physical cores, capped by affinity and the cgroup's CPU quota)")
@@ -169,54 +179,77 @@ def end_to_end(eng, args):
     nfiles, reads = args.e2e_files, args.e2e_reads
     threads = cpu_budget()["usable_cores"]
     tmp = Path(tempfile.mkdtemp(prefix="vk_e2e_"))
-    out = {"files": nfiles, "reads_per_file": reads, "read_len": args.readlen, "io_threads": threads}
+    # the files (plain + gzip, ~1.3x the text) must fit the temporary directory, and the text the page cache
+    rec = 2 * args.readlen + 20
+    free = shutil.disk_usage(tmp).free
     try:
-        fq, offs, lens = eng.synth(1 << 20, nfiles, reads, args.readlen, dist=args.dist)
-        host = fq.cpu().numpy()
-        del fq
+        with open("/proc/meminfo") as f:
+            avail = next(int(l.split()[1]) * 1024 for l in f if l.startswith("MemAvailable"))
+    except Exception:
+        avail = free
+    room = min(free, avail // 2)
+    while nfiles > 16 and nfiles * reads * rec * 1.35 > room:
+        nfiles //= 2
+    out = {"files": nfiles, "files_asked": args.e2e_files, "reads_per_file": reads, "read_len": args.readlen,
+           "io_threads": threads}
+    try:
+        # generated on the device in slabs of 32 files and copied back (a 46 GB tensor at once would also do,
+        # but the pool of the main measurement is still resident)
+        host_parts, offs, lens = [], [], []
+        for f0 in range(0, nfiles, 32):
+            nf = min(32, nfiles - f0)
+            fq, o, l = eng.synth((1 << 20) + f0, nf, reads, args.readlen, dist=args.dist)
+            host_parts.append((fq.cpu().numpy(), o, l))
+            del fq
+        torch.cuda.empty_cache()
         kb = reads * args.readlen // 1000
         plain = [tmp / f"s{i:04d}@{kb:08d}K.fq" for i in range(nfiles)]
         gz = [tmp / "gz" / f"s{i:04d}@{kb:08d}K.fq.gz" for i in range(nfiles)]
         (tmp / "gz").mkdir()
 
         def write(i):
-            blob = host[int(offs[i]):int(offs[i]) + int(lens[i])]
+            host, o, l = host_parts[i // 32]
+            blob = host[int(o[i % 32]):int(o[i % 32]) + int(l[i % 32])]
             blob.tofile(plain[i])
             co = zlib.compressobj(1, zlib.DEFLATED, 31)       # gzip container, fast level
             with open(gz[i], "wb") as f:
                 f.write(co.compress(blob.tobytes()) + co.flush())
         with ThreadPoolExecutor(threads) as ex:
             list(ex.map(write, range(nfiles)))
-        text_bytes = int(sum(int(x) for x in lens))
+        text_bytes = nfiles * reads * rec
         gz_bytes = sum(p.stat().st_size for p in gz)
-        del host
+        del host_parts
         bases = nfiles * reads * args.readlen
-        # (batches: 2 GiB of text for plain files, so that reading the next batch overlaps the copy of this one;
-        # 16 GiB for gzip files, whose staging is cheap and whose inflate wants many files in flight)
-        for name, files, moved, bb in (("plain_text", plain, text_bytes, 2 << 30), ("fq_gz", gz, gz_bytes, 16 << 30)):
-            dst = tmp / ("img_" + name)
+        # batch sizes are the pipeline's own defaults (what `python -m varkoder_amd image` runs with)
+        for name, files, moved in (("plain_text", plain, text_bytes), ("fq_gz", gz, gz_bytes)):
             # one untimed pass first: staging buffers and device workspaces are allocated once per process
             pipeline.fastqs_to_images(files, tmp / ("warm_" + name), k=args.k, mapping_code=args.mapping,
-                                      io_threads=threads, engine=eng, batch_bytes=bb)
-            # two timed passes (the second into a fresh folder); the faster one is quoted, both are listed
-            passes = []
-            for rep in range(2):
-                if rep:
-                    dst = tmp / ("img2_" + name)
+                                      io_threads=threads, engine=eng)
+            shutil.rmtree(tmp / ("warm_" + name), ignore_errors=True)
+            # timed passes, each into a fresh folder; the MEDIAN is quoted, all are listed
+            passes, parts = [], []
+            for rep in range(max(1, args.e2e_passes)):
+                dst = tmp / ("img%d_%s" % (rep, name))
+                tm = {}
                 t0 = time.perf_counter()
                 stats = pipeline.fastqs_to_images(files, dst, k=args.k, mapping_code=args.mapping, io_threads=threads,
-                                                  engine=eng, batch_bytes=bb)
+                                                  engine=eng, timings=tm)
                 passes.append(time.perf_counter() - t0)
-            dst = tmp / ("img_" + name)
-            dt = min(passes)
+                parts.append(tm)
+            order = sorted(range(len(passes)), key=lambda i: passes[i])
+            mid = order[len(order) // 2]
+            dt = passes[mid]
+            dst = tmp / ("img0_" + name)
             ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
             out[name] = {"seconds": dt, "passes_s": passes, "gbases_per_s": bases / dt / 1e9, "files_per_s": nfiles / dt,
                          "file_bytes": moved, "file_gb_per_s": moved / dt / 1e9, "text_gb_per_s": text_bytes / dt / 1e9,
-                         "batch_bytes": bb, "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png")))}
+                         "batch_bytes": "pipeline default", "all_files_ok": ok, "pngs": len(list(dst.rglob("*.png"))),
+                         "where_the_median_pass_went_s": {k: round(v, 4) if isinstance(v, float) else v
+                                                          for k, v in parts[mid].items()}}
         # the two routes must give the same images
         same = 0
-        for p in sorted((tmp / "img_plain_text").rglob("*.png")):
-            q = tmp / "img_fq_gz" / p.name
+        for p in sorted((tmp / "img0_plain_text").rglob("*.png")):
+            q = tmp / "img0_fq_gz" / p.name
             same += int(q.is_file() and q.read_bytes() == p.read_bytes())
         out["gz_pngs_identical_to_plain"] = same == nfiles
         # the link itself, for scale: one pinned 1 GiB buffer, host to device
@@ -229,11 +262,78 @@ def end_to_end(eng, args):
             dev.copy_(pin, non_blocking=True)
         torch.cuda.synchronize()
         out["pcie_h2d_gb_per_s_pinned_1GiB"] = 4 * (1 << 30) / (time.perf_counter() - t0) / 1e9
-        out["note"] = ("files -> PNGs, page cache warm, one GPU, the faster of two passes; .fq.gz files stay compressed in the "
+        out["note"] = ("files -> PNGs, page cache warm, one GPU, the median of the timed passes; the breakdown is the "
+                       "main thread's wall time (staging of the next batch runs beside it); .fq.gz files stay compressed in the "
                        "pinned staging buffer, the inflate kernels read them over PCIe and write the text to HBM "
                        "(vk_inflate_device)")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def config4(args, device_index):
+    """BASELINE.json configs[3] as a side leg of the N=1 line: k=9 cgr images (512x512), 1M 150 bp reads
+    per sample, 100 samples, every sample distinct (pool = samples), for the uniform and the GC-skew +
+    homopolymer base distribution.  4^9 u32 counters do not fit LDS: this is the spill path
+    (vk_bucket_kernel -> vk_bucket_order_kernel -> vk_bucket_count_kernel -> vk_bucket_merge_kernel).
+    Times are HIP events on the launch stream around the count and the image call; `frac` is against the
+    same HBM peak as the main line (algorithmic bytes = text read once + the 1 MiB histogram written once
+    per sample); `traffic` and the per-kernel times come from profiles/k9_latest.json when that file was
+    taken on this configuration, else null."""
+    import torch
+    from varkoder_amd.engine import ImageEngine
+    n, k = args.config4_samples, 9
+    eng = ImageEngine(k=k, mapping="cgr", device=device_index)
+    dev = torch.device("cuda", device_index)
+    ncode = 4 ** k
+    out = {"workload": "BASELINE configs[3]: k=9 cgr (%dx%d), %d distinct samples x %d x %d bp reads, 1 GPU, FASTQ "
+                       "text resident in HBM" % (eng.side, eng.side, n, args.reads, args.readlen),
+           "samples": n, "steps": args.config4_steps, "k": k, "mapping": "cgr"}
+    prof = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "k9_latest.json")) as f:
+            prof = json.load(f)
+    except Exception:
+        prof = None
+    hist = torch.empty((n, ncode), dtype=torch.int32, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    img = torch.empty((n, eng.side, eng.side), dtype=torch.uint8, device=dev)
+    buf = None
+    for dist_code in (0, 1):
+        buf, offs, lens = eng.synth(7000, n, args.reads, args.readlen, dist=dist_code, out=buf)
+        eng.count(buf, offs, lens, hist=hist, status=status)      # warm-up: workspaces are allocated here
+        eng.images(hist, img=img)
+        torch.cuda.synchronize()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.config4_steps)]
+        t0 = time.perf_counter()
+        for e in ev:
+            e[0].record()
+            eng.count(buf, offs, lens, hist=hist, status=status)
+            e[1].record()
+            eng.images(hist, img=img)
+            e[2].record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / len(ev)
+        count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        image_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        alg = n * (int(lens[0]) + 4 * ncode)
+        leg = {"ms_per_step": wall * 1e3, "count_ms": count_ms, "image_ms": image_ms,
+               "gbases_per_s": n * args.reads * args.readlen / wall / 1e9,
+               "bad_status_samples": int((status != 0).sum().item()), "count_launch": eng.last_count_launch(),
+               "roofline": {"bound": "hbm", "kernel": "vk_bucket_kernel + vk_bucket_count_kernel + vk_bucket_merge_kernel",
+                            "achieved": alg / (count_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (count_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                            "traffic": None, "kernel_ms_profiled": None}}
+        want = {"k": k, "samples": n, "reads": args.reads, "readlen": args.readlen, "pool": n, "dist": dist_code}
+        for entry in (prof or {}).get("legs", []):
+            if entry.get("config") == want:
+                leg["roofline"]["traffic"] = entry.get("hbm_bytes_per_launch")
+                leg["roofline"]["kernel_ms_profiled"] = entry.get("kernel_ms")
+                leg["roofline"]["profile"] = entry.get("tag")
+        out["dist%d" % dist_code] = leg
+    eng.close()
+    del buf, hist, img, status
+    torch.cuda.empty_cache()
     return out
 
 
@@ -376,8 +476,13 @@ def main():
         step(ev[i])
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # per-rank times: an imbalance must be visible in the record
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -407,6 +512,10 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the kernel the count call launches (rocprofv3's name for it): k <= 7 the sequence-only dense kernel
+        # unless VKIMG_K1_CLASSIC=1 asks for the kernel that classifies every byte; k = 8, 9 the spill path
+        count_kernel = ("vk_bucket_kernel+vk_bucket_count_kernel+vk_bucket_merge_kernel" if args.k > 7 else
+                        "vk_count_kernel" if os.environ.get("VKIMG_K1_CLASSIC") == "1" else "vk_count_dense_kernel")
         out = {
             "metric": "Gbases/s for `varKoder image` k=%d, %d bp reads" % (args.k, args.readlen),
             "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
@@ -426,20 +535,27 @@ def main():
                        "distinct_samples_in_hbm": pool, "base_distribution": args.dist,
                        "fastq_bytes_per_sample": fastq_bytes, "parallelism": "samples sharded x%d" % world,
                        "count_launch": eng.last_count_launch()},
-            "kernel_ms": {"vk_count_kernel(+check)": count_ms, "vk_image_kernel": image_ms},
+            "ms_per_step_by_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            "kernel_ms": {count_kernel + "(+check)": count_ms, "vk_image_kernel": image_ms},
             "bad_status_samples": bad,
-            "roofline": {"bound": "hbm", "kernel": "vk_count_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": count_kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": count_ms},
         }
+        if world == 1 and not args.no_config4 and args.k <= 7:
+            try:
+                out["config4"] = config4(args, local_rank)
+            except Exception as e:  # a side measurement: never lose the bench line over it
+                out["config4"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(eng, fastq, poffs, plens, args, args.cpu_seconds)
             except Exception as e:  # the baseline is a reported side figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e:
-            del hist, img           # make room: the end-to-end run allocates its own batches
+            del hist, img, fastq    # make room: the end-to-end run allocates its own batches
+            torch.cuda.empty_cache()
             try:
                 out["end_to_end"] = end_to_end(eng, args)
             except Exception as e:  # a side measurement: never lose the bench line over it

@@ -37,7 +37,8 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
         pmc.setdefault(kern, {})[ctr] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v)}
 json.dump(pmc, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
-ck = next((k for k in pmc if k.startswith("vk_count_kernel")), None)
+ck = next((k for k in pmc if k.startswith("vk_count_dense_kernel")), None) or \
+    next((k for k in pmc if k.startswith("vk_count_kernel")), None)
 if ck and "FETCH_SIZE" in pmc[ck] and "WRITE_SIZE" in pmc[ck]:
     fetch = pmc[ck]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2   # KB -> B, gfx950 x2
     write = pmc[ck]["WRITE_SIZE"]["mean_per_dispatch"] * 1024

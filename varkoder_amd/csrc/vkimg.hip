@@ -54,8 +54,11 @@ struct vk_ctx {
     // workspaces (grown on demand, never inside a timed launch after warm-up)
     uint64_t* d_desc = nullptr;   // offsets | lengths
     size_t desc_cap = 0;
-    uint64_t* h_desc = nullptr;   // pinned mirror of d_desc (descriptor cache)
+    uint64_t* h_desc = nullptr;   // pinned mirror of d_desc (descriptor cache): the copy uploaded last
     size_t h_desc_cap = 0;
+    uint64_t* h_desc_alt = nullptr;  // the other of the two mirrors: a batch with new descriptors is staged here
+    size_t h_desc_alt_cap = 0;       // while the previous batch's copy may still be reading h_desc
+    hipEvent_t desc_ev = nullptr, desc_ev_alt = nullptr;  // recorded behind the copy out of each mirror
     uint32_t desc_n = 0;
     uint32_t* d_wavephase = nullptr;
     size_t wavephase_cap = 0;
@@ -120,18 +123,35 @@ int upload_desc(vk_ctx* ctx, const uint64_t* offsets, const uint64_t* lengths, u
     if (ctx->desc_n == n && ctx->h_desc && memcmp(ctx->h_desc, offsets, bytes) == 0 &&
         memcmp(ctx->h_desc + n, lengths, bytes) == 0)
         return VK_OK;
-    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a previous upload may still read h_desc
-    if (ctx->h_desc_cap < 2 * bytes) {
-        if (ctx->h_desc) VK_HIP(ctx, hipHostFree(ctx->h_desc));
-        ctx->h_desc = nullptr;
-        ctx->h_desc_cap = 0;
-        VK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_desc), 2 * bytes + 4096, hipHostMallocDefault));
-        ctx->h_desc_cap = 2 * bytes + 4096;
+    // Two pinned mirrors take turns: the new descriptors go into the one that was NOT uploaded last, and
+    // the host waits only for the copy that read that mirror two batches ago (an event behind it) -- not,
+    // as a stream synchronise would, for every kernel queued since (a pipeline's batches all differ).
+    uint64_t* m = ctx->h_desc_alt;
+    size_t cap = ctx->h_desc_alt_cap;
+    hipEvent_t ev = ctx->desc_ev_alt;
+    if (ev) VK_HIP(ctx, hipEventSynchronize(ev));
+    if (cap < 2 * bytes) {
+        if (m) VK_HIP(ctx, hipHostFree(m));
+        m = nullptr;
+        cap = 0;
+        ctx->h_desc_alt = nullptr;
+        ctx->h_desc_alt_cap = 0;
+        VK_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&m), 2 * bytes + 4096, hipHostMallocDefault));
+        cap = 2 * bytes + 4096;
     }
-    memcpy(ctx->h_desc, offsets, bytes);
-    memcpy(ctx->h_desc + n, lengths, bytes);
+    if (!ev) VK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    memcpy(m, offsets, bytes);
+    memcpy(m + n, lengths, bytes);
+    VK_HIP(ctx, hipMemcpyAsync(ctx->d_desc, m, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    // swap: what was uploaded just now becomes the cache the next call compares against
+    ctx->h_desc_alt = ctx->h_desc;
+    ctx->h_desc_alt_cap = ctx->h_desc_cap;
+    ctx->desc_ev_alt = ctx->desc_ev;
+    ctx->h_desc = m;
+    ctx->h_desc_cap = cap;
+    ctx->desc_ev = ev;
     ctx->desc_n = n;
-    VK_HIP(ctx, hipMemcpyAsync(ctx->d_desc, ctx->h_desc, 2 * bytes, hipMemcpyHostToDevice, ctx->stream));
     return VK_OK;
 }
 
@@ -328,6 +348,9 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+    if (ctx->h_desc_alt) (void)hipHostFree(ctx->h_desc_alt);
+    if (ctx->desc_ev) (void)hipEventDestroy(ctx->desc_ev);
+    if (ctx->desc_ev_alt) (void)hipEventDestroy(ctx->desc_ev_alt);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -190,7 +190,7 @@ class ImageEngine:
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
                 "paths": [str(p) for p in paths]}
 
-    def upload_staged(self, staged):
+    def upload_staged(self, staged, timings=None):
         """Device half: one H2D DMA of the plain text, one of the compressed files, and the gzip files
         inflated in HBM into their text slots (vk_inflate_device).  Returns (tensor, offsets, lengths);
         the staging buffer may be refilled once this returns.  A gzip file the GPU rejects (bad header
@@ -207,8 +207,12 @@ class ImageEngine:
             # staging buffer, over PCIe (each byte once by the block-start finder and once by the decoder,
             # ~12 GB/s of a 57 GB/s link) -- 27 ms of H2D copy per 1.5 GB that nothing had to wait for
             gzdev = pinned[plain_total:stage_total]
+            import time
+            ti = time.perf_counter()
             got, st = self.inflate(gzdev, staged["src"][gi] - np.uint64(plain_total), staged["disk"][gi], dev,
                                    offs[gi], staged["caps"][gi])
+            if timings is not None:
+                timings["inflate_s"] = timings.get("inflate_s", 0.0) + time.perf_counter() - ti
             over = [j for j in range(gi.size) if st[j] == _capi.VK_GZ_OVERFLOW]
             if over:
                 # more text than the last member's size word promised (a multi-member file): inflate those

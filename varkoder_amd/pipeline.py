@@ -17,17 +17,31 @@ from .image import counts_name, eprint, png_name, shard_folder, write_png
 from .shard import shard_indices
 
 
+# Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
+# the copy of this one.  gzip files are inflated on the GPU, which wants many files in flight, and their
+# staging is cheap: larger batches.  The first batch of a run is cut short so that the device has work
+# while the bulk of the files is still being read.  (bench.py's end-to-end leg runs with these defaults.)
+DEFAULT_BATCH_BYTES = 2 << 30
+DEFAULT_GZ_BATCH_BYTES = 16 << 30
+FIRST_BATCH_BYTES = 512 << 20
+
+
 def image_name(fastq_path, k, mapping_code):
     """`<sample>@<bp>K+<mapping>+k<k>.png` straight from a split FASTQ's name."""
     return png_name(counts_name(fastq_path, k), mapping_code)
 
 
 def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_sd=None, overwrite=False,
-                     subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=2 << 30, io_threads=8,
-                     engine=None, verbose=False):
+                     subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=None, io_threads=8,
+                     engine=None, verbose=False, timings=None):
     """Process this rank's share of `files`.  Returns {sample_file_stem: OrderedDict(stats)}
     with the reference's stats keys `<k>mer_counting_time` and `k<k>_img_time` (per-file
-    share of the batch wall time) or `failed_step` for files whose FASTQ framing is bad."""
+    share of the batch wall time) or `failed_step` for files whose FASTQ framing is bad.
+    batch_bytes: None = DEFAULT_BATCH_BYTES (DEFAULT_GZ_BATCH_BYTES when every file is gzip).
+    timings: optional dict that receives where this thread's wall time went (seconds): waiting for the
+    staging thread (`stage_wait_s`), the copy to the device and the inflate (`upload_s`, of which
+    `inflate_s`), kernels + copies back (`kernels_s`), handing images to the PNG pool (`png_submit_s`)
+    and waiting for the last PNGs (`png_tail_s`); `batches`."""
     from .engine import ImageEngine
     files = [Path(f) for f in files]
     labels = labels or {}
@@ -53,11 +67,16 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         todo.append(f)
 
     import os
+    if batch_bytes is None:
+        batch_bytes = DEFAULT_GZ_BATCH_BYTES if todo and all(f.suffix == ".gz" for f in todo) else DEFAULT_BATCH_BYTES
+    tm = timings if timings is not None else {}
+    for key in ("stage_wait_s", "upload_s", "inflate_s", "kernels_s", "png_submit_s", "png_tail_s"):
+        tm.setdefault(key, 0.0)
     # batches by text size in HBM (gzip files count 6x their size on disk: they are inflated on the GPU)
     batches, batch, nbytes = [], [], 0
     for f in todo:
         sz = os.path.getsize(f) * (6 if f.suffix == ".gz" else 1)
-        if batch and nbytes + sz > batch_bytes:
+        if batch and nbytes + sz > (min(batch_bytes, FIRST_BATCH_BYTES) if not batches else batch_bytes):
             batches.append((batch, nbytes))
             batch, nbytes = [], 0
         batch.append(f)
@@ -71,15 +90,19 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     for bi, (batch, nbytes) in enumerate(batches):
         t0 = time.perf_counter()
         ready = staged.result()
+        tm["stage_wait_s"] += time.perf_counter() - t0
         if bi + 1 < len(batches):
             staged = stager.submit(eng.stage_files, batches[bi + 1][0], pool, (bi + 1) & 1)
-        dev, offs, lens = eng.upload_staged(ready)
+        tu = time.perf_counter()
+        dev, offs, lens = eng.upload_staged(ready, timings=tm)
         t1 = time.perf_counter()
+        tm["upload_s"] += t1 - tu
         img, hist, status = eng.fastq_to_images(dev, offs, lens)
         st = status.cpu().numpy()
         imgs = img.cpu().numpy()
         nz = (hist != 0).any(dim=1).cpu().numpy()
         t2 = time.perf_counter()
+        tm["kernels_s"] += t2 - t1
         for j, f in enumerate(batch):
             key = str(f.name.removesuffix("".join(f.suffixes)))
             s = stats.setdefault(key, OrderedDict())
@@ -95,12 +118,16 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
             pending.append((key, time.perf_counter(),
                             pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
                                         QUAL_THRESH, mapping_code)))
+        tm["png_submit_s"] += time.perf_counter() - t2
         if verbose:
             eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
     stager.shutdown()
+    tt = time.perf_counter()
     for key, t, fut in pending:
         fut.result()
         stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t
+    tm["png_tail_s"] += time.perf_counter() - tt
+    tm["batches"] = tm.get("batches", 0) + len(batches)
     pool.shutdown()
     if engine is None:
         eng.close()
@@ -108,7 +135,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
 
 
 def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp=None, is_query=False, seeds=None,
-                    labels=None, base_sd=None, subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=2 << 30,
+                    labels=None, base_sd=None, subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=None,
                     io_threads=8, engine=None, verbose=False):
     """Steps C+D+E of run_clean2img (commands/image.py:1006-1127) for cleaned, UNSPLIT read files
     `<sample>.fq[.gz]` (the reference's `<int_folder>/clean_reads/`): the 1-2-5 ladder of subsamples
@@ -132,6 +159,8 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
     stats = OrderedDict()
     pool = ThreadPoolExecutor(io_threads)
     pending = []
+    if batch_bytes is None:
+        batch_bytes = DEFAULT_GZ_BATCH_BYTES if mine and all(f.suffix == ".gz" for f in mine) else DEFAULT_BATCH_BYTES
     i = 0
     while i < len(mine):
         batch, nbytes = [], 0

@@ -109,7 +109,12 @@ static uint32_t vko_sample_hash(uint64_t seed, uint64_t anchor) {
 }
 
 /* vko_count_fastq over the taken reads only.  sites[0] = bytes of all sequence lines (the
- * reference's nsites, image.py:669-675: len(line) - 1), sites[1] = of the taken reads' lines. */
+ * reference's nsites, image.py:669-675: len(line) - 1), sites[1] = of the taken reads' lines.
+ * The reference draws its subsamples with `reformat.sh ... breaklength=500` (image.py:586-588):
+ * BBTools cuts a read longer than 500 bases into pieces of 500 before sampling, so no k-mer of a
+ * subsample spans a multiple of 500 bases of its read -- restated here as a window reset at every
+ * such position (VKO_BREAK_LENGTH). */
+#define VKO_BREAK_LENGTH 500
 int vko_count_fastq_sampled(const uint8_t* buf, size_t n, int k, uint64_t seed, uint64_t threshold,
                             uint32_t* fwd, uint64_t* nwin, uint64_t* sites) {
     if (k < 1 || k > 15 || !fwd || threshold > (1ull << 32)) return VKO_EINVAL;
@@ -135,6 +140,7 @@ int vko_count_fastq_sampled(const uint8_t* buf, size_t n, int k, uint64_t seed, 
                 int run = 0;
                 for (size_t i = pos; i < e; i++) {
                     int c = base_code(buf[i]);
+                    if ((i - pos) % VKO_BREAK_LENGTH == 0) run = 0;
                     if (c < 0) { run = 0; continue; }
                     fw = ((fw << 2) | (uint32_t)c) & mask;
                     if (++run >= k) { fwd[fw]++; windows++; }

@@ -95,6 +95,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
             const long long o0 = (long long)w0 - 64;
             const uint64_t npieces = (w1 - w0 + 64 + kPiece - 1) / kPiece;
             uint32_t carry_c = 0, carry_bad = 0x55555555u, pph = 0, sub_carry = 0;
+            long long read_start_rel = 0;  // where the sequence line running into the piece starts, relative to the piece
             for (uint64_t it = 0; it < npieces; ++it) {
                 uint8_t piece[kPiece];
                 for (int i = 0; i < kPiece; ++i) {
@@ -122,7 +123,9 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                 if (sub && sub->on && it == 0 && w0 != 0 && (pph & 3u) == 1u) {
                     const uint64_t a = last_newline_before(s, (uint64_t)o0);
                     sub_carry = (a != ~0ull && vkl::sample_take(sub->seed, a, sub->threshold)) ? 1u : 0u;
+                    read_start_rel = a != ~0ull ? (long long)(a + 1) - o0 : 0;
                 }
+                long long rstart = read_start_rel;  // lanes run in order: the kernel's fetch from the nearest anchor lane
                 for (int lane = 0; lane < 64; ++lane) {
                     const uint32_t lph = (pph + excl) & 3u;
                     excl += c[lane];
@@ -141,14 +144,25 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     if (sub && sub->on) {
                         // lanes run in order here, so the max-scan of the kernel is a running value
                         const uint64_t base = (uint64_t)(o0 + (long long)it * kPiece) + 64ull * lane;
-                        uint32_t first[4], inc[4], anchors, take;
+                        uint32_t first[4], inc[4], anchors, take, seq_at;
                         if (any_gt3 || any_eq4) {
+                            uint32_t la;
                             anchors = vkl::sample_strings_general(lb[lane].NL, lph, base, sub->seed, sub->threshold,
-                                                                  first, inc, take);
+                                                                  first, inc, take, la);
+                            seq_at = la + 1u;
                         } else {
                             anchors = (lph != 1u && s_raw <= 64u) ? 1u : 0u;
                             take = (anchors && vkl::sample_take(sub->seed, base + s_raw - 1u, sub->threshold)) ? 1u : 0u;
                             for (int g = 0; g < 4; ++g) { first[g] = anchors ? 0u : ~0u; inc[g] = take ? ~0u : 0u; }
+                            seq_at = s_raw;
+                        }
+                        {   // breaklength: no window over a multiple of 500 bases of the read the block begins in
+                            const uint32_t rel0 = (uint32_t)(64ll * lane - rstart);
+                            uint32_t q1, lo2, hi2;
+                            vkl::break_stretches<K>(rel0 % vkl::kBreakLength, q1, lo2, hi2);
+                            const vkl::Mask128 m1 = vkl::ones_below(q1), m2a = vkl::ones_not_below(lo2), m2b = vkl::ones_below(hi2);
+                            for (int g = 0; g < 4; ++g) ok[g] &= ~(((m2a.w[g] & m2b.w[g]) | m1.w[g]) & first[g]);
+                            if (anchors) rstart = 64ll * lane + seq_at;
                         }
                         const uint32_t inh = 0u - sub_carry;
                         if (anchors) sub_carry = take;
@@ -166,6 +180,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
                     vkl::windows<K>(ch, lb[lane].C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; }, [] {});
                 }
                 pph += total;
+                read_start_rel = rstart - kPiece;
             }
             prev_end = pph & 3u;
         }

@@ -266,3 +266,52 @@ def test_c_abi_from_plain_c(tmp_path):
     want, nwin, st = oracle.fastq_to_image(data, 7, pixel_lut(7, "cgr"), 128 * 128)
     assert st == 0 and np.array_equal(got, want)
     assert f"{nwin} k-mer windows" in res.stdout
+
+
+def test_cli_image_at_world_two_equals_single_rank(tmp_path):
+    """The product entry under a launcher: `torchrun --nproc-per-node 2 -m varkoder_amd image ...` (both
+    ranks on cuda:0 here, started by torch.distributed.run BEFORE anything touches the GPU) writes the
+    same PNG files and the same merged stats.csv rows as a single-rank run -- samples are sharded
+    round-robin, rank 0 merges the per-sample stats (reference: commands/image.py:1281-1284, 1144-1170)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    split = tmp_path / "int" / "split_fastqs"
+    split.mkdir(parents=True)
+    for i in range(7):
+        _write_fastq(split / f"tax{i}_S@{150 * (1 + i % 3):08d}K.fq{'.gz' if i % 2 else ''}", 70 + i, 1000 * (1 + i % 3),
+                     gz=bool(i % 2))
+    (split / "broken_Z@00000150K.fq").write_bytes(b"this is not a FASTQ file\n" * 50)   # one bad sample never kills the run
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "LOCAL_WORLD_SIZE")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    common = ["image", str(tmp_path / "int"), "-k", "7", "-p", "varKode", "-n", "2"]
+    one = subprocess.run([sys.executable, "-m", "varkoder_amd"] + common +
+                         ["-o", str(tmp_path / "img1"), "-f", str(tmp_path / "stats1.csv")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "varkoder_amd"] + common +
+                         ["-o", str(tmp_path / "img2"), "-f", str(tmp_path / "stats2.csv")],
+                         capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(env, VARKODER_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    a = sorted(p.name for p in (tmp_path / "img1").rglob("*.png"))
+    b = sorted(p.name for p in (tmp_path / "img2").rglob("*.png"))
+    assert a == b and len(a) == 7
+    for name in a:
+        assert next((tmp_path / "img1").rglob(name)).read_bytes() == next((tmp_path / "img2").rglob(name)).read_bytes()
+    s1, s2 = pd.read_csv(tmp_path / "stats1.csv"), pd.read_csv(tmp_path / "stats2.csv")
+    assert list(s1["sample"]) == list(s2["sample"]) and len(s1) == 8
+    assert list(s1.columns) == list(s2.columns)
+    assert list(s1["failed_step"].fillna("")) == list(s2["failed_step"].fillna(""))
+    assert s2.set_index("sample").loc["broken_Z", "failed_step"] == "image"
+    timed = [c for c in s2.columns if c.endswith("_time")]
+    assert timed and (s2.set_index("sample").drop("broken_Z")[timed] > 0).all().all()

@@ -57,6 +57,29 @@ def test_oracle_rule_on_a_hand_case():
     assert seen == {0, 10, 20}
 
 
+def _break_case():
+    """Reads of 1200, 500, 501 and 499 bases (no N): reformat.sh breaklength=500 (commands/image.py:586-588)
+    cuts them into 500 + 500 + 200, 500, 500 + 1 and 499."""
+    rng = np.random.default_rng(500)
+    reads = ["".join(rng.choice(list("ACGT"), size=n)) for n in (1200, 500, 501, 499)]
+    return b"".join(fastq_cases.rec("r%d" % i, r) for i, r in enumerate(reads)), reads
+
+
+def test_no_window_of_a_subsample_spans_a_multiple_of_500_bases():
+    """Hand case for breaklength=500: the windows of a read are the windows of its 500-base pieces."""
+    data, reads = _break_case()
+    for k in (5, 7, 9):
+        fwd, nwin, st, sites = oracle.count_fastq_sampled(data, k, 1, 1 << 32)
+        pieces = [r[i:i + 500] for r in reads for i in range(0, len(r), 500)]
+        want = sum(max(0, len(p) - k + 1) for p in pieces)
+        assert st == 0 and nwin == want and sites == (2700, 2700)
+        # ... which are exactly the windows of a file that holds the pieces as reads of their own
+        broken = b"".join(fastq_cases.rec("p%d" % i, p) for i, p in enumerate(pieces))
+        assert np.array_equal(fwd, oracle.count_fastq(broken, k)[0])
+        # the unsampled count (split files: already broken by step C) is untouched by the rule
+        assert oracle.count_fastq(data, k)[1] == sum(len(r) - k + 1 for r in reads)
+
+
 def _engine(k):
     from varkoder_amd.engine import ImageEngine
     return ImageEngine(k=k, mapping="cgr")
@@ -169,3 +192,30 @@ def test_cli_from_clean_writes_the_ladder(tmp_path):
     assert list(df["sample"]) == ["sampA", "sampB"]
     assert list(df["splitting_bp_per_file"]) == ["2000000,1000000,500000", "1200000,1000000,500000"]
     assert {"7mer_counting_time", "k7_img_time", "splitting_time"} <= set(df.columns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", (5, 7, 8, 9))
+def test_breaklength_on_the_gpu(k):
+    """vk_count_sampled_device applies reformat.sh's breaklength=500: hand case and long ragged reads, every
+    split of the samples into byte ranges."""
+    data, _ = _break_case()
+    rng = np.random.default_rng(9)
+    long_reads = b"".join(fastq_cases.rec("L%d" % i, "".join(rng.choice(list("ACGTN"), size=int(n),
+                                                                            p=[.24, .24, .24, .24, .04])))
+                          for i, n in enumerate(rng.integers(1, 6000, size=400)))
+    eng = _engine(k)
+    try:
+        blobs = [data, long_reads, data * 200]
+        dev, offs, lens = eng.upload(blobs)
+        for seed, thr in ((3, 1 << 32), (4, 1 << 31)):
+            for parts in (0, 1, 3):
+                hist, status, sites = eng.count_sampled(dev, offs, lens, seed, thr, parts=parts)
+                got = hist.cpu().numpy().view(np.uint32)
+                for i, b in enumerate(blobs):
+                    want, nwin, st, wsites = oracle.count_fastq_sampled(b, k, seed, thr)
+                    assert st == 0 and int(status.cpu()[i]) == 0
+                    assert tuple(int(x) for x in sites.cpu().numpy()[i]) == wsites, (i, parts)
+                    assert np.array_equal(got[i], want), (k, i, seed, parts)
+    finally:
+        eng.close()

@@ -217,7 +217,7 @@ def run_image_from_clean(args, outdir, rank, world, local_rank):
     import numpy as np
     import pandas as pd
     from .pipeline import clean_to_images
-    from .shard import gather_stats
+    from .shard import gather_stats, io_threads_per_rank
     src = Path(args.input)
     if (src / "clean_reads").is_dir():
         src = src / "clean_reads"
@@ -236,7 +236,7 @@ def run_image_from_clean(args, outdir, rank, world, local_rank):
     per_sample = clean_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping,
                                  min_bp=parse_size(args.min_bp), max_bp=max_bp, seeds=seeds, labels=labels,
                                  base_sd=base_sd,
-                                 device=local_rank, rank=rank, world=world, io_threads=max(1, args.n_threads) * 4,
+                                 device=local_rank, rank=rank, world=world, io_threads=io_threads_per_rank(args.n_threads),
                                  verbose=args.verbose)
     for s, v in per_sample.items():
         v["base_frequencies_sd"] = base_sd.get(s, 0)
@@ -259,7 +259,7 @@ def run_image_from_clean(args, outdir, rank, world, local_rank):
 def run_image(args):
     import pandas as pd
     from .pipeline import fastqs_to_images
-    from .shard import gather_stats, world_info
+    from .shard import gather_stats, io_threads_per_rank, world_info
     if args.kmer_size not in range(KMER_MIN, KMER_MAX + 1):
         raise ValueError("kmer size must be between 5 and 9")               # image.py:1209-1210
     rank, world, local_rank = world_info()
@@ -302,7 +302,7 @@ def run_image(args):
         return
     per_file = fastqs_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping, labels=labels,
                                 base_sd=base_sd, overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
-                                world=world, io_threads=max(1, args.n_threads) * 4, verbose=args.verbose)
+                                world=world, io_threads=io_threads_per_rank(args.n_threads), verbose=args.verbose)
     # fold the per-file stats into per-sample stats like run_clean2img does (image.py:1057-1125)
     mine = defaultdict(OrderedDict)
     ck, ik = f"{args.kmer_size}mer_counting_time", f"k{args.kmer_size}_img_time"

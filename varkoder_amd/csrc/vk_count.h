@@ -482,6 +482,7 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, 
     uint32_t carry_c = 0u, carry_bad = 0x55555555u;
     uint32_t pph = 0;  // line phase at the start of the current piece
     uint32_t sub_carry = 0u;  // SUB: is the read that runs into the current piece taken?
+    int32_t read_start_rel = 0;  // SUB: where that read's sequence line starts, relative to the current piece (<= 0)
     auto tbl_below = [&](uint32_t q) {
         uint4 v = below[q];
         vkl::Mask128 m;
@@ -559,21 +560,46 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, 
                 // the range is entered inside a sequence line whose header ended before the pre-block
                 const uint64_t a = last_newline_before(sbase, o0, lane);
                 sub_carry = (a != ~0ull && vkl::sample_take(sw.seed, a, sw.threshold)) ? 1u : 0u;
+                // (a read more than 2 GiB long would wrap this: such a sequence line is not FASTQ anyone subsamples)
+                read_start_rel = a != ~0ull ? static_cast<int32_t>(static_cast<int64_t>(a + 1) - static_cast<int64_t>(o0)) : 0;
             }
-            uint32_t first[4], inc[4], anchors, take;
+            uint32_t first[4], inc[4], anchors, take, seq_at;  // seq_at: block position where the last anchor's read starts
             if (degenerate || four) {  // several reads may meet in one block: position by position
-                anchors = vkl::sample_strings_general(lb.NL, lph, base, sw.seed, sw.threshold, first, inc, take);
+                uint32_t la;
+                anchors = vkl::sample_strings_general(lb.NL, lph, base, sw.seed, sw.threshold, first, inc, take, la);
+                seq_at = la + 1u;
             } else {
                 anchors = (lph != 1u && s_raw <= 64u) ? 1u : 0u;
                 take = (anchors && vkl::sample_take(sw.seed, base + s_raw - 1u, sw.threshold)) ? 1u : 0u;
                 const uint32_t f = anchors ? 0u : 0xFFFFFFFFu, n = take ? 0xFFFFFFFFu : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) { first[g] = f; inc[g] = n; }
+                seq_at = s_raw;  // (a block with an anchor on this tier begins outside a sequence line: nothing of the read before)
             }
             const uint32_t v = anchors ? (((static_cast<uint32_t>(lane) + 1u) << 1) | take) : 0u;
             const uint32_t scan = wave_inclusive_max(v);
-            const uint32_t inherited = max(wave_prev_lane(scan, 0u), sub_carry) & 1u;
+            const uint32_t pscan = wave_prev_lane(scan, 0u);
+            const uint32_t inherited = max(pscan, sub_carry) & 1u;
             sub_carry = max(lane_bcast(scan, 63), sub_carry) & 1u;
+            // breaklength (vkl::kBreakLength): where, relative to this piece, does the sequence line start that the
+            // block begins in?  Behind the nearest anchor of an earlier lane, else where the piece before left it.
+            const int32_t my_start = static_cast<int32_t>(lane64 + seq_at);
+            const uint32_t alane = (pscan >> 1) - 1u;
+            const int32_t from_lane = __builtin_amdgcn_ds_bpermute(static_cast<int>(alane << 2), my_start);
+            const int32_t rstart = pscan != 0u ? from_lane : read_start_rel;
+            {
+                const uint32_t last = lane_bcast(scan, 63);
+                const int32_t at_last = __builtin_amdgcn_readlane(my_start, static_cast<int>(((last >> 1) - 1u) & 63u));
+                read_start_rel = (last != 0u ? at_last : read_start_rel) - static_cast<int32_t>(kPiece);
+            }
+            {
+                const uint32_t rel0 = static_cast<uint32_t>(static_cast<int32_t>(lane64) - rstart);  // read position of the block's first byte
+                uint32_t q1, lo2, hi2;
+                vkl::break_stretches<K>(rel0 % vkl::kBreakLength, q1, lo2, hi2);
+                const vkl::Mask128 m1 = tbl_below(q1), m2a = tbl_above(lo2), m2b = tbl_below(hi2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ok[g] &= ~(((m2a.w[g] & m2b.w[g]) | m1.w[g]) & first[g]);
+            }
             const uint32_t inh = 0u - inherited;
             // the pre-block belongs to the previous range; bytes at or beyond w1 are zero fill
             const bool mine = !(it == 0 && lane == 0 && has_pre) && base < w1;

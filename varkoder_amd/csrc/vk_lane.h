@@ -322,9 +322,11 @@ VKL_FN bool sample_take(uint64_t seed, uint64_t anchor, uint64_t threshold) {
 // the block has none) -- they belong to the read the block was entered in; `inc` = positions after
 // an anchor whose read is taken.  Returns anchors seen; last_take = decision of the last one.
 VKL_FN uint32_t sample_strings_general(const uint32_t NL[4], uint32_t lph, uint64_t base, uint64_t seed,
-                                       uint64_t threshold, uint32_t first[4], uint32_t inc[4], uint32_t& last_take) {
+                                       uint64_t threshold, uint32_t first[4], uint32_t inc[4], uint32_t& last_take,
+                                       uint32_t& last_anchor) {
     uint32_t cur = lph & 3u, anchors = 0, take = 0;
     last_take = 0;
+    last_anchor = 0;  // block position of the last anchor (meaningful when the return value is not 0)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
@@ -342,6 +344,7 @@ VKL_FN uint32_t sample_strings_general(const uint32_t NL[4], uint32_t lph, uint6
                     ++anchors;
                     take = sample_take(seed, base + 16u * static_cast<uint32_t>(g) + (b >> 1), threshold) ? 1u : 0u;
                     last_take = take;
+                    last_anchor = 16u * static_cast<uint32_t>(g) + (b >> 1);
                 }
                 cur = (cur + 1u) & 3u;
             }
@@ -350,6 +353,19 @@ VKL_FN uint32_t sample_strings_general(const uint32_t NL[4], uint32_t lph, uint6
         inc[g] = n;
     }
     return anchors;
+}
+
+// reformat.sh breaks reads longer than this into pieces before anything else sees them (the reference
+// runs it with breaklength=500, commands/image.py:586-588): no k-mer of a subsample spans a multiple of
+// 500 bases of its read.  Block positions p whose window would: ((r + p) mod 500) <= K - 2, r = read
+// position of the block's first byte mod 500 -- at most two stretches in 64 positions.  Returns the
+// bounds of [0, q1) and [lo2, hi2) as the mask tables take them.
+constexpr uint32_t kBreakLength = 500;
+template <int K>
+VKL_FN void break_stretches(uint32_t r, uint32_t& q1, uint32_t& lo2, uint32_t& hi2) {
+    q1 = r <= static_cast<uint32_t>(K - 2) ? static_cast<uint32_t>(K - 1) - r : 0u;
+    lo2 = umin(kBreakLength - r, 64u);
+    hi2 = umin(lo2 + static_cast<uint32_t>(K - 1), 64u);
 }
 
 VKL_FN Mask128 ones_not_below(uint32_t q) {

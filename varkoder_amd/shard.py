@@ -12,8 +12,45 @@ from collections import OrderedDict
 
 
 def world_info():
+    """(rank, world size, device index of this rank).  The device is LOCAL_RANK -- one process per GPU --
+    unless VARKODER_AMD_DEVICE names one for every rank (a two-rank rehearsal on a one-GPU box)."""
+    dev = os.environ.get("VARKODER_AMD_DEVICE")
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
-            int(os.environ.get("LOCAL_RANK", "0")))
+            int(dev) if dev not in (None, "") else int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def usable_cores():
+    """Cores this process may really use: scheduler affinity, capped by the cgroup's CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                tok = f.read().split()
+            if path.endswith("cpu.max"):
+                if tok[0] != "max":
+                    n = min(n, max(1, int(float(tok[0]) / float(tok[1]) + 0.5)))
+            else:
+                q = float(tok[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / float(g.read().split()[0]) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def io_threads_per_rank(n_threads):
+    """Host threads of one rank's file pipeline: the reference's -n is a per-node figure
+    (commands/image.py:1281-1284 sizes ONE pool with it), so the ranks of a node share it -- 4 I/O
+    threads per requested core as before, but never more than this rank's share of the cores the
+    job may use (usable cores // LOCAL_WORLD_SIZE): eight ranks on a 16-core quota get 2 each, not 8 x 4n."""
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    share = max(1, usable_cores() // local_world)
+    return max(1, min(max(1, int(n_threads)) * 4, share if local_world > 1 else max(share, 1) * 4))
 
 
 def shard_indices(n_items, rank, world):

@@ -121,8 +121,12 @@ int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* o
  * d_gz is memory the device can read: HBM, or pinned host memory (hipHostMalloc) -- the kernels then read the
  * compressed bytes over PCIe where they lie (twice: block-start finder and decoder) and no copy is needed
  * (single-member files: the little-endian u32 in the file's last four bytes is the text length).
- * Multi-member files and zero padding after the last member are accepted.  out_lengths[i] (host)
- * receives the bytes written and status[i] (host) the VK_GZ_* bits; the call synchronises.
+ * Multi-member files are accepted; after a complete member, zero padding or bytes that are not a gzip
+ * header end the data (as for zlib's gzread, which is how dsk reads a .gz).  out_lengths[i] (host)
+ * receives the bytes written and status[i] (host) the VK_GZ_* bits; the call synchronises.  A file whose
+ * text does not fit out_caps[i] gets VK_GZ_OVERFLOW and no text; where the whole file was decoded before the
+ * slot was looked at (files of 512 KiB and more) out_lengths[i] then holds the size a second call needs
+ * (> out_caps[i]), otherwise the bytes that fitted.
  * Integrity: structure and every member's ISIZE are checked; the trailer's CRC-32 is verified (on the GPU)
  * for files that consist of one member, which is what the reference's pipeline writes. */
 int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,

@@ -310,3 +310,87 @@ def test_inflate_chunk_sizes_and_false_block_starts(monkeypatch):
             eng.close()
         assert status.tolist() == [0, 0], cb
         assert got[0] == texts[0] and got[1] == texts[1], cb
+
+
+def bgzf(data, block=30000, level=6):
+    """A BGZF file (bgzip; what BBTools writes through bgzip): members of at most 64 KiB with a 'BC' extra
+    field that holds the member's size, and an empty member at the end."""
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = data[i:i + block] if i is not None else b""
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                   struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
+
+
+def test_many_member_files_are_sized_up_front_and_inflated_once(engines, tmp_path):
+    """A BGZF file of more than 1000 members ends with an empty member (ISIZE 0): the text slot comes from a
+    walk over the block headers (engine.bgzf_text_size), not from the file's last four bytes, so the file is
+    inflated ONCE; a plain concatenation of members (no size fields to walk) is inflated a second time into
+    a slot of the size the first pass reported; bytes after the last member that are not gzip are ignored, as
+    zlib's gzread (dsk) and gzip(1) ignore them."""
+    from oracle import oracle
+    from varkoder_amd import engine as engine_mod
+    eng = engines(7)
+    big = synth.sample_fastq(11, 110000, 150, dist=1).tobytes()          # 35 MB: 1174 members of 30000 B
+    small = synth.sample_fastq(12, 3000, 150).tobytes()
+    files = {"bgzf_big.fq.gz": bgzf(big), "bgzf_small.fq.gz": bgzf(small, block=65280),
+             "concat.fq.gz": b"".join(gz(big[i:i + 3_000_000], 1) for i in range(0, len(big), 3_000_000)),
+             "rle_members.fq.gz": gz(b"@r\n" + b"A" * 4_000_000 + b"\n+\n" + b"I" * 4_000_000 + b"\n", 9) + gz(small),
+             "garbage_tail.fq.gz": gz(small) + b"\x00\x00not a gzip member at all" * 3,
+             "plain_single.fq.gz": gz(small, 1)}
+    assert len(bgzf(big)) > 0 and engine_mod.bgzf_text_size(files["bgzf_big.fq.gz"]) == len(big)
+    assert files["bgzf_big.fq.gz"].count(b"\x1f\x8b\x08\x04") >= 1000
+    want = {"bgzf_big.fq.gz": big, "bgzf_small.fq.gz": small, "concat.fq.gz": big,
+            "rle_members.fq.gz": b"@r\n" + b"A" * 4_000_000 + b"\n+\n" + b"I" * 4_000_000 + b"\n" + small,
+            "garbage_tail.fq.gz": small, "plain_single.fq.gz": small}
+    for name, blob in files.items():
+        (tmp_path / name).write_bytes(blob)
+        if name != "garbage_tail.fq.gz":
+            assert gzip.decompress(blob) == want[name]
+    calls = []
+    real = eng.inflate
+
+    def counting(gzbuf, go, gl, out, oo, oc):
+        calls.append(len(go))
+        return real(gzbuf, go, gl, out, oo, oc)
+    eng.inflate = counting
+    try:
+        for names in (["bgzf_big.fq.gz", "bgzf_small.fq.gz", "plain_single.fq.gz"], ["concat.fq.gz"],
+                      ["rle_members.fq.gz", "garbage_tail.fq.gz"]):
+            calls.clear()
+            dev, offs, lens = eng.upload_files([tmp_path / n for n in names])
+            text = dev.cpu().numpy()
+            for n, o, ln in zip(names, offs, lens):
+                assert bytes(text[int(o):int(o) + int(ln)]) == want[n], n
+            if names[0].startswith("bgzf"):
+                assert calls == [3], calls              # one inflate call, nothing inflated twice
+            elif names[0] == "concat.fq.gz":
+                assert calls == [1, 1], calls           # once more, into a slot of the size the first pass reported
+            else:
+                assert calls == [2, 1, 1], calls        # 35:1 over a small file: the 32x slot overflows too, 256x holds it
+            hist, status = eng.count(dev, offs, lens)
+            for i, n in enumerate(names):
+                wh, _, st = oracle.count_fastq(want[n], 7)
+                assert st == 0 and int(status.cpu()[i]) == 0
+                assert np.array_equal(hist.cpu().numpy().view(np.uint32)[i], wh), n
+    finally:
+        eng.inflate = real
+
+
+def test_a_truncated_gzip_file_cannot_reserve_gigabytes(engines, tmp_path):
+    """The last four bytes of a truncated .fq.gz are arbitrary: the text slot is capped at 64x the file's size,
+    the file comes out empty with a status, its batch mates are untouched."""
+    eng = engines(7)
+    a = synth.sample_fastq(5, 3000, 150).tobytes()
+    good = gz(a)
+    cut = good[: len(good) * 2 // 3 - 4] + b"\xff\xff\xff\xf0"           # "ISIZE" = 4 GiB - 256 MiB
+    (tmp_path / "good.fq.gz").write_bytes(good)
+    (tmp_path / "cut.fq.gz").write_bytes(cut)
+    st = eng.stage_files([tmp_path / "cut.fq.gz", tmp_path / "good.fq.gz"])
+    assert int(st["caps"][0]) <= 64 * len(cut) + (1 << 16) and int(st["caps"][1]) == len(a)
+    dev, offs, lens = eng.upload_staged(st)
+    assert int(lens[0]) == 0 and int(lens[1]) == len(a)
+    assert bytes(dev.cpu().numpy()[int(offs[1]):int(offs[1]) + len(a)]) == a

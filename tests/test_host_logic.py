@@ -134,7 +134,7 @@ def test_file_pipeline_batches_and_overlaps_without_a_gpu(tmp_path):
             blobs = [p.read_bytes() for p in paths]
             return blobs, slot
 
-        def upload_staged(self, staged):
+        def upload_staged(self, staged, timings=None):
             blobs, slot = staged
             log.append(("upload", slot))
             lens = np.array([len(b) for b in blobs], dtype=np.uint64)
@@ -230,3 +230,28 @@ def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
     assert st["offs"][1] == 0 and bytes(host[:len(good)]) == good   # plain text first, at its final offset
     assert st["src"][0] >= st["plain_total"] and bytes(host[int(st["src"][0]):int(st["src"][0]) + len(zbytes)]) == zbytes
     assert st["offs"][0] >= st["plain_total"] and st["text_total"] % 16 == 0
+
+
+def test_bgzf_text_size_walks_block_headers():
+    """engine.bgzf_text_size: the text size of a BGZF file without inflating it; None for anything else."""
+    import gzip
+    import struct
+    import zlib
+    from varkoder_amd.engine import bgzf_text_size
+
+    def bgzf(data, block):
+        out = []
+        for i in list(range(0, len(data), block)) + [None]:
+            chunk = data[i:i + block] if i is not None else b""
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            raw = co.compress(chunk) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) +
+                       raw + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        return b"".join(out)
+    data = b"@r\nACGTACGT\n+\nIIIIIIII\n" * 20000
+    blob = bgzf(data, 30000)
+    assert gzip.decompress(blob) == data and blob[-4:] == b"\x00\x00\x00\x00"      # the end marker's ISIZE
+    assert bgzf_text_size(blob) == len(data)
+    assert bgzf_text_size(np.frombuffer(blob, dtype=np.uint8)) == len(data)
+    assert bgzf_text_size(gzip.compress(data)) is None          # one ordinary member: its own size word is right
+    assert bgzf_text_size(blob + b"junk") is None and bgzf_text_size(blob[:-5]) is None and bgzf_text_size(b"") is None

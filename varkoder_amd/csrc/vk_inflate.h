@@ -805,9 +805,18 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                 while ((pos >> 3) < nbytes && in[pos >> 3] == 0) pos += 8;
                 if ((pos >> 3) >= nbytes) break;
             }
-            if ((pos >> 3) + 18 > nbytes) { st |= any_member ? kGzTruncated : kGzBadHeader; break; }
+            // After a complete member, bytes that are not another gzip header end the data: zlib's gzread (how
+            // dsk reads a .gz) and gzip(1) decode the members and ignore trailing garbage.
+            if ((pos >> 3) + 18 > nbytes) {
+                if (!any_member) st |= kGzBadHeader;
+                else if ((pos >> 3) + 2 <= nbytes && in[pos >> 3] == 0x1f && in[(pos >> 3) + 1] == 0x8b) st |= kGzTruncated;
+                break;
+            }
             const uint8_t* h = in + (pos >> 3);
-            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) { st |= kGzBadHeader; break; }
+            if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xE0)) {
+                if (!any_member || (h[0] == 0x1f && h[1] == 0x8b)) st |= kGzBadHeader;  // (a gzip magic with a method or flags no gzip has: damaged, not garbage)
+                break;
+            }
             const uint32_t flg = h[3];
             uint64_t p = (pos >> 3) + 10;
             if (flg & 4) {  // FEXTRA

@@ -720,6 +720,7 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             if (ok && isum != static_cast<uint32_t>(total)) ok = false;  // the members' size words do not add up to the text
             if (ok && total > out_caps[i]) {  // e.g. several members and a caller who knew only the last one's size
                 status[i] = VK_GZ_OVERFLOW;
+                out_lengths[i] = total;       // ... who now learns the size a second call needs
                 items.resize(mark);
                 continue;
             }
@@ -753,9 +754,13 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             hipLaunchKernelGGL(vk_gzwin_kernel, dim3(nf), dim3(1024), 0, ctx->stream, reinterpret_cast<uint16_t*>(ctx->d_gzsym),
                                d_items, d_first, d_count, ctx->d_gzwin);
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(vk_gzfinal_kernel, dim3(32, ni), dim3(256), 0, ctx->stream,
-                               reinterpret_cast<uint16_t*>(ctx->d_gzsym), d_items, ni, ctx->d_gzwin, out);
-            VK_HIP(ctx, hipGetLastError());
+            for (uint32_t i0 = 0; i0 < ni; i0 += 65535u) {  // (gridDim.y holds 65535 at most: 8 GiB of 128 KiB chunks)
+                const uint32_t n = ni - i0 < 65535u ? ni - i0 : 65535u;
+                hipLaunchKernelGGL(vk_gzfinal_kernel, dim3(32, n), dim3(256), 0, ctx->stream,
+                                   reinterpret_cast<uint16_t*>(ctx->d_gzsym), d_items + i0, n,
+                                   ctx->d_gzwin + static_cast<size_t>(i0) * 32768, out);
+                VK_HIP(ctx, hipGetLastError());
+            }
             VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (items / first / count are read by the kernels)
         }
     }

@@ -18,6 +18,37 @@ def _torch():
     return torch
 
 
+def bgzf_text_size(buf):
+    """Text bytes of a BGZF file (what `bgzip` and BBTools-through-bgzip write: gzip members of at most
+    64 KiB, each with its own size in a 'BC' extra field), summed over the members' ISIZE words by hopping
+    from block header to block header -- no inflating.  None when `buf` is not BGZF from end to end.  The
+    last member of such a file is an empty one (ISIZE 0), so the size word that ends the FILE says nothing
+    about the text."""
+    n = len(buf)
+    pos = total = 0
+    mv = memoryview(buf)
+    while pos < n:
+        if pos + 18 > n:
+            return None
+        h = bytes(mv[pos:pos + 18])
+        if h[0] != 0x1F or h[1] != 0x8B or h[2] != 8 or not (h[3] & 4) or h[10] != 6 or h[11] != 0 or h[12:16] != b"BC\x02\x00":
+            return None
+        size = (h[16] | (h[17] << 8)) + 1
+        if size < 26 or pos + size > n:
+            return None
+        total += int.from_bytes(bytes(mv[pos + size - 4:pos + size]), "little")
+        pos += size
+    return total if n else None
+
+
+# A gzip file's text slot in HBM is reserved before anything is inflated.  The size word that ends the file
+# (ISIZE) is the size of its LAST member modulo 2^32 -- right for what split_fastq writes, arbitrary bytes
+# in a truncated file: never reserve more than this many times the file's size on disk (+ slack); a file
+# that really expands further overflows its slot and is inflated again into one of the size the first pass
+# reported (vk_inflate_device, VK_GZ_OVERFLOW).
+GZ_MAX_FIRST_RATIO = 64
+
+
 class ImageEngine:
     """FASTQ (in HBM) -> forward k-mer histograms -> uint8 images, for one k and mapping.
 
@@ -144,21 +175,17 @@ class ImageEngine:
         disk = np.array([d for _, d, _ in info], dtype=np.uint64)
         lens = np.array([0 if g else t for g, _, t in info], dtype=np.uint64)      # gzip: known after the inflate
         caps = np.array([t for _, _, t in info], dtype=np.uint64)                  # text slot sizes
-        # text layout: plain files first, then the slots of the gzip files
+        for i in np.flatnonzero(is_gz):
+            caps[i] = min(int(caps[i]), GZ_MAX_FIRST_RATIO * int(disk[i]) + (1 << 16))
+        # staging layout: the plain files at their final 16-byte aligned text offsets, then the compressed files
         offs = np.zeros(n, dtype=np.uint64)
         pos = 0
         for i in np.flatnonzero(~is_gz):
             offs[i] = pos
             pos += (int(caps[i]) + 15) // 16 * 16
         plain_total = pos
-        for i in np.flatnonzero(is_gz):
-            offs[i] = pos
-            pos += (int(caps[i]) + 15) // 16 * 16
-        text_total = pos + 16
-        # staging layout: the plain region as it will sit on the device, then the compressed files
         src = np.zeros(n, dtype=np.uint64)
         src[~is_gz] = offs[~is_gz]
-        pos = plain_total
         for i in np.flatnonzero(is_gz):
             src[i] = pos
             pos += (int(disk[i]) + 15) // 16 * 16
@@ -184,8 +211,20 @@ class ImageEngine:
                     disk[i] = 0
                     lens[i] = 0
                     caps[i] = 0
+                elif is_gz[i] and nb >= 28 and host[o + 3] & 4:
+                    # many-member files (BGZF): the text size is the sum over the members, found by walking
+                    # the block headers -- not the last member's size word (0 for BGZF's empty end marker)
+                    t = bgzf_text_size(host[o:o + nb])
+                    if t is not None:
+                        caps[i] = t
             host[o + nb:(o + nb + 15) // 16 * 16] = 0
         list(mapper(fill, range(n)))
+        # text layout in HBM: the plain region as staged, then the slots of the gzip files
+        pos = plain_total
+        for i in np.flatnonzero(is_gz):
+            offs[i] = pos
+            pos += (int(caps[i]) + 15) // 16 * 16
+        text_total = pos + 16
         return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
                 "paths": [str(p) for p in paths]}
@@ -213,21 +252,35 @@ class ImageEngine:
                                    offs[gi], staged["caps"][gi])
             if timings is not None:
                 timings["inflate_s"] = timings.get("inflate_s", 0.0) + time.perf_counter() - ti
-            over = [j for j in range(gi.size) if st[j] == _capi.VK_GZ_OVERFLOW]
-            if over:
-                # more text than the last member's size word promised (a multi-member file): inflate those
-                # again into a side buffer with room for 32x their compressed size and append it
+            # More text than the slot held (several members and only the last one's size word known, or a
+            # file that expands past GZ_MAX_FIRST_RATIO): inflate those again into a side buffer -- of the
+            # size the first pass reported where it could (the chunked path decodes the whole file before it
+            # looks at the slot), else of 32x, 256x and finally DEFLATE's limit of 1032x the compressed size.
+            tried = {j: int(staged["caps"][gi[j]]) for j in range(gi.size)}   # the slot size of each file's last attempt
+            for grow in (32, 256, 1032):
+                over = [j for j in range(gi.size) if st[j] == _capi.VK_GZ_OVERFLOW]
+                if not over:
+                    break
                 oi = gi[over]
-                c2 = staged["disk"][oi] * np.uint64(32) + np.uint64(1 << 16)
+                # (a length beyond the slot is the size the call reported as needed; one within it is what fitted)
+                c2 = np.array([int(got[jj]) if int(got[jj]) > tried[jj] else
+                               int(staged["disk"][gi[jj]]) * grow + (1 << 16) for jj in over], dtype=np.uint64)
+                for j, jj in enumerate(over):
+                    tried[jj] = int(c2[j])
                 o2 = np.zeros(oi.size, dtype=np.uint64)
                 p = 0
                 for j in range(oi.size):
                     o2[j] = p
                     p += (int(c2[j]) + 15) // 16 * 16
-                side = torch.empty(p + 16, dtype=torch.uint8, device=self.device)
+                try:
+                    side = torch.empty(p + 16, dtype=torch.uint8, device=self.device)
+                except RuntimeError as e:       # no room for that much text: these files fail, the batch lives
+                    print("gzip inflate: no memory for", p, "bytes of text:", repr(e)[:120], file=sys.stderr)
+                    break
                 g2, s2 = self.inflate(gzdev, staged["src"][oi] - np.uint64(plain_total), staged["disk"][oi], side, o2, c2)
                 base = dev.numel()
                 dev = torch.cat([dev, side])
+                del side
                 for j, jj in enumerate(over):
                     got[jj], st[jj] = g2[j], s2[j]
                     offs = offs.copy() if offs is staged["offs"] else offs

@@ -26,14 +26,21 @@ def needs_build():
     return os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps)
 
 
+LAST = {}  # what the last build_hip() call did: {"action": "compiled" | "reused", "so": path, "so_mtime": ..., "seconds": ...}
+
+
 def build_hip(force=False, verbose=False):
+    import time
     if not force and not needs_build():
+        LAST.update(action="reused", so=OUT, so_mtime=os.path.getmtime(OUT), seconds=0.0)
         return OUT
+    t0 = time.time()
     cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-I", INC, SRC, "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    LAST.update(action="compiled", so=OUT, so_mtime=os.path.getmtime(OUT), seconds=time.time() - t0)
     return OUT
 
 

@@ -235,6 +235,7 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
                 a[2 * j + 1] = ((x >> 16) & kMask4) + lds_base;  // position i
             }
             unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+            const unsigned long long exec_in = __builtin_amdgcn_read_exec();  // restored behind the block (the callers run with every lane active)
             asm volatile(
                 "v_add_co_u32_e64 %0, %1, %0, %0\n\t"
                 "v_add_co_u32_e64 %0, %2, %0, %0\n\t"
@@ -252,9 +253,9 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
                 "s_mov_b64 exec, %6\n\tds_add_u32 %14, %17\n\t"
                 "s_mov_b64 exec, %7\n\tds_add_u32 %15, %17\n\t"
                 "s_mov_b64 exec, %8\n\tds_add_u32 %16, %17\n\t"
-                "s_mov_b64 exec, -1"
+                "s_mov_b64 exec, %18"
                 : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
-                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one)
+                : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one), "s"(exec_in)
                 : "memory");
             if (g == 3 && half == 1) {
                 probe_addr = a[7];
@@ -763,6 +764,7 @@ __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t o
             a[2 * j + 1] = ((x >> 16) & kMask4) + lds_base;
         }
         unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+        const unsigned long long exec_in = __builtin_amdgcn_read_exec();
         asm volatile(
             "v_add_co_u32_e64 %0, %1, %0, %0\n\t"
             "v_add_co_u32_e64 %0, %2, %0, %0\n\t"
@@ -780,9 +782,9 @@ __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t o
             "s_mov_b64 exec, %6\n\tds_add_u32 %14, %17\n\t"
             "s_mov_b64 exec, %7\n\tds_add_u32 %15, %17\n\t"
             "s_mov_b64 exec, %8\n\tds_add_u32 %16, %17\n\t"
-            "s_mov_b64 exec, -1"
+            "s_mov_b64 exec, %18"
             : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
-            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one), "s"(exec_in)
             : "memory");
         if (half == 1) {
             probe_addr = a[7];
@@ -1252,6 +1254,7 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
             uint32_t a0, a1, a2, a3;
             unsigned long long m0, m1, m2, m3, k0, k1, k2, k3;
             const uint32_t cap = kQueueBytes;
+            const unsigned long long exec_in = __builtin_amdgcn_read_exec();  // put back behind the block, whatever it was
             asm volatile(
                 "v_cmp_ne_u32_e64 %[m0], 0, %[f0]\n\t"
                 "v_cmp_ne_u32_e64 %[m1], 0, %[f1]\n\t"
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                 "s_mov_b64 exec, %[m3]\n\ts_waitcnt lgkmcnt(3)\n\t"
                 "v_cmp_gt_u32_e64 %[k3], %[cap], %[a3]\n\tv_lshl_add_u32 %[a3], %[c3], 6, %[a3]\n\t"
                 "s_mov_b64 exec, %[k3]\n\tds_write_b16 %[a3], %[e3] offset:%[qb]\n\t"
-                "s_mov_b64 exec, -1\n\t"
+                "s_mov_b64 exec, %[ex]\n\t"
                 "s_andn2_b64 %[m0], %[m0], %[k0]\n\t"
                 "s_andn2_b64 %[m1], %[m1], %[k1]\n\t"
                 "s_andn2_b64 %[m2], %[m2], %[k2]\n\t"
@@ -1282,7 +1285,7 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                   [m2] "=&s"(m2), [m3] "=&s"(m3), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)
                 : [f0] "v"(f[0]), [f1] "v"(f[1]), [f2] "v"(f[2]), [f3] "v"(f[3]), [c0] "v"(c[0]), [c1] "v"(c[1]),
                   [c2] "v"(c[2]), [c3] "v"(c[3]), [e0] "v"(e[0]), [e1] "v"(e[1]), [e2] "v"(e[2]), [e3] "v"(e[3]),
-                  [two] "v"(two), [cap] "s"(cap), [qb] "i"(kLdsQueues)
+                  [two] "v"(two), [cap] "s"(cap), [qb] "i"(kLdsQueues), [ex] "s"(exec_in)
                 : "memory");
             // m_j now holds the lanes whose pair j found its queue full
             if ((m0 | m1 | m2 | m3) == 0ull) return 0u;  // wave-uniform; the rule

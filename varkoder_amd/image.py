@@ -75,7 +75,8 @@ def base_sd_table(clean_reads_dir, samples):
 
 
 def read_fastq_bytes(infile):
-    """Whole FASTQ text of a plain or gzip-compressed file (dsk reads .gz natively)."""
+    """Whole FASTQ text of a plain or gzip-compressed file, on the HOST (tests and tools; the product reads
+    files through ImageEngine.upload_files, where a .gz is inflated on the GPU)."""
     p = Path(infile)
     with open(p, "rb") as f:
         head = f.read(2)

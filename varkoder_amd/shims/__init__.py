@@ -57,30 +57,26 @@ def dsk_main(argv=None):
         raise SystemExit(f"dsk (varkoder_amd shim): k-mer size {k} is outside 5..9")
     if int(opts.get("-abundance-min", 1)) != 1:
         raise SystemExit("dsk (varkoder_amd shim): only -abundance-min 1 (no filtering) is supported")
-    import ctypes as C
-
     import numpy as np
 
-    from .. import _capi
-    from ..image import read_fastq_bytes, write_counts
-    data = read_fastq_bytes(opts["-file"])
-    L = _capi.lib()
-    ctx = C.c_void_p()
-    _capi.check(None, L.vk_ctx_create(int(os.environ.get("VARKODER_AMD_DEVICE", "0")), None, 1, C.byref(ctx)),
-                "vk_ctx_create")
+    from ..engine import ImageEngine
+    from ..image import write_counts
+    # the file goes the product's own way: as it is on disk into pinned memory, a .gz inflated on the GPU by
+    # vk_inflate_device (one gzip decoder in the product: no host gzip beside it that could disagree with it)
+    eng = ImageEngine(k=k, mapping="cgr", device=int(os.environ.get("VARKODER_AMD_DEVICE", "0")))
     try:
-        buf = np.frombuffer(data, dtype=np.uint8)
-        hist = np.empty(4 ** k, dtype=np.uint32)
-        stw = C.c_uint32(0)
-        st = L.vk_count_host(ctx, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, k,
-                             hist.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(stw))
-        if st == _capi.VK_EFORMAT or stw.value:
-            print(f"dsk (varkoder_amd shim): inconsistent FASTQ framing in {opts['-file']} "
-                  f"(status bits {stw.value})", file=sys.stderr)
+        dev, offs, lens = eng.upload_files([opts["-file"]])
+        if os.path.getsize(opts["-file"]) and not int(lens[0]):
+            print(f"dsk (varkoder_amd shim): {opts['-file']} is not a readable FASTQ / gzip file", file=sys.stderr)
             return 1
-        _capi.check(ctx, st, "vk_count_host")
+        h, st = eng.count(dev, offs, lens)
+        hist, stw = h.cpu().numpy().view(np.uint32)[0].copy(), int(st.cpu()[0])
+        if stw:
+            print(f"dsk (varkoder_amd shim): inconsistent FASTQ framing in {opts['-file']} "
+                  f"(status bits {stw})", file=sys.stderr)
+            return 1
     finally:
-        L.vk_ctx_destroy(ctx)
+        eng.close()
     write_counts(counts_path(opts["-out"]), k, hist)
     return 0
 

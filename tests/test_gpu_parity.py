@@ -350,3 +350,41 @@ def test_dense_stage_matches_oracle_and_classic_kernel(engines, k):
         got = hist.cpu().numpy().view(np.uint32)
         bad = [i for i in range(len(blobs)) if not np.array_equal(got[i], want[i])]
         assert not bad, (k, parts, bad)
+
+
+@pytest.mark.parametrize("k", (5, 6, 7, 8, 9))
+def test_tandem_repeats_of_every_short_period_stay_exact(engines, k):
+    """Microsatellite-like input: reads that are tandem repeats of period 1..9 (seen at every phase, mixed
+    motifs, broken by N, of odd lengths, next to ordinary reads).  The k <= 7 kernels count the lane groups that
+    repeat with ONE add per residue class (windows_lds_hot), everything else as usual: same histograms."""
+    from fastq_cases import rec
+    rng = np.random.default_rng(700 + k)
+    motifs = ["A", "AC", "ACG", "ACGT", "AACGT", "ACGTTG", "ACGGTCA", "ACGTTGCA", "ACGTTGCAT", "GT", "TTAGGG", "CAG"]
+    recs, i = [], 0
+    for block in range(36):
+        m = motifs[block % len(motifs)]
+        for _ in range(int(rng.integers(150, 500))):
+            n = int(rng.integers(20, 260))
+            ph = int(rng.integers(0, len(m)))
+            seq = ((m * 300)[ph: ph + n])
+            r = rng.random()
+            if r < 0.1:
+                seq = seq[: n // 2] + "N" + seq[n // 2 + 1:]
+            elif r < 0.2:
+                seq = "".join(rng.choice(list("ACGT"), size=n))
+            elif r < 0.25:
+                seq = seq[: n // 3] + (motifs[(block + 5) % len(motifs)] * 300)[: n - n // 3]   # the motif changes inside the read
+            recs.append(rec(f"t{i}" + "x" * int(rng.integers(0, 40)), seq))
+            i += 1
+    fq = b"".join(recs)
+    uniform = b"".join(rec("u%07d" % j, ("ACGT" * 40)[:150]) for j in range(20000))   # every record 320 bytes, one phase
+    eng = engines(k)
+    dev, offs, lens = eng.upload([fq, uniform, fq[::1]])
+    wants = [oracle.count_fastq(b, k)[0] for b in (fq, uniform)]
+    for parts in (1, 2):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got = hist.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[0], wants[0]), (k, parts)
+        assert np.array_equal(got[1], wants[1]), (k, parts)
+        assert np.array_equal(got[2], wants[0]), (k, parts)

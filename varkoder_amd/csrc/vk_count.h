@@ -265,17 +265,35 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
     }
 }
 
-// Low-complexity input (poly-A tails, short tandem repeats): when most lanes of a position hold the SAME
-// k-mer, their ds_add serialise on one LDS counter (64 lanes: ~15x the cost of a scattered add).  The
-// piece loop therefore probes one position per piece -- do at least 7 of 8 counting lanes agree? -- and
-// while they do, counts the following pieces with this loop instead: per position the lanes that agree
-// with the first counting lane are added by that lane in one go (popcount), up to four such groups, and
-// whatever is left goes one by one.  Exact either way; ordinary reads never enter it.
+// Low-complexity input (poly-A tails, short tandem repeats): when the lanes of a position hold one or a few
+// distinct k-mers, their ds_add serialise on a few LDS counters (64 lanes on one: ~15x the cost of a scattered
+// add).  The piece loop therefore probes one position per piece -- do at least 7 of 8 counting lanes agree? --
+// and, every sixteenth piece, whether the counting lanes fall into at most eight groups (a tandem repeat of
+// period <= 8 seen at different phases); while the data looks like that, pieces are counted by
+// windows_lds_hot: whole homopolymer pieces with one add per lane, lane groups (16 positions) that repeat with
+// a short period with one add per residue class, everything else as usual.  Exact either way; ordinary reads
+// never enter it.
 __device__ __forceinline__ bool probe_is_hot(uint32_t addr, unsigned long long mask) {
     if (__builtin_popcountll(mask) < 8) return false;
     const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(addr), __builtin_ctzll(mask)));
     const unsigned long long eq = __ballot(addr == first) & mask;
     return __builtin_popcountll(eq) * 8 >= __builtin_popcountll(mask) * 7;
+}
+
+__device__ __forceinline__ bool probe_few_groups(uint32_t addr, unsigned long long mask) {
+    if (__builtin_popcountll(mask) < 24) return false;
+    unsigned long long rem = mask;
+    for (int n = 0; n < 8 && rem; ++n) {
+        const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(addr), __builtin_ctzll(rem)));
+        rem &= ~__ballot(addr == first);
+    }
+    return rem == 0ull;
+}
+
+// The two probes together; `tick` counts the calls of one wave.
+__device__ __forceinline__ bool probe_low_complexity(uint32_t addr, unsigned long long mask, uint32_t& tick) {
+    if (probe_is_hot(addr, mask)) return true;
+    return ((++tick) & 15u) == 0u && probe_few_groups(addr, mask);
 }
 
 // Is, in EVERY lane of the wave, every base under a counting window one and the same base?  Then every
@@ -311,45 +329,106 @@ __device__ __forceinline__ bool piece_is_homopolymer(uint32_t ch, const uint32_t
     return __all(homo);
 }
 
-template <int K>
-__device__ void windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok[4], uint32_t* hist, int lane,
-                                uint32_t& probe_addr, unsigned long long& probe_mask) {
-    // the probe for the next piece: the window that ends at position 40 of every lane
+// Tandem repeats.  The period P (1..8 bases) is read off one lane whose first 32 positions are all countable;
+// a lane group g (16 positions, every window countable) repeats with it when the bases its windows cover --
+// the last K - 1 of the word before and its own sixteen -- equal themselves P positions on.  Then the window
+// ending at position 16g + j (j < P) stands for every position of the group that is congruent to j:
+// add(field, n) is called for it, by ONE lane for all lanes that hold the same field there (all of them when the
+// reads sit alike in their blocks, P sets otherwise: 64 adds on one counter would be executed one after the
+// other), n = the positions it stands for.  Such groups leave ok[]; what remains (read ends, other reads) is for
+// the caller to count as usual.  Returns how many groups of this lane went this way.
+template <int K, typename Add>
+__device__ __forceinline__ uint32_t count_repeats(const uint32_t (&v)[5], uint32_t (&ok)[4], int lane, Add add) {
+    uint32_t P = 0, handled = 0;
     {
-        const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
-        constexpr int P = 40, o = 30 + 2 * (P - K + 1), word = o >> 5, sh = o & 31;
-        constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+        const unsigned long long cand = __ballot(ok[0] == 0x55555555u && ok[1] == 0x55555555u);
+        if (cand != 0ull) {
+            const int src = __builtin_ctzll(cand);
+            const unsigned long long x = (static_cast<unsigned long long>(lane_bcast(v[2], src)) << 32) | lane_bcast(v[1], src);
+#pragma unroll
+            for (uint32_t p = 8; p >= 1; --p)
+                if ((((x >> (2u * p)) ^ x) << (2u * p)) == 0ull) P = p;  // bits [0, 64 - 2p) of the difference
+        }
+    }
+    if (P == 0u) return 0u;
+    const uint32_t sh2 = 2u * P;
+    const uint32_t himask = 0xFFFFFFFFu >> sh2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t lo = v[g], hi = v[g + 1];
+        const uint32_t dlo = (vkl::alignbit(hi, lo, sh2) ^ lo) & (0xFFFFFFFFu << (32 - 2 * (K - 1)));
+        const uint32_t dhi = ((hi >> sh2) ^ hi) & himask;
+        const bool rep = ok[g] == 0x55555555u && (dlo | dhi) == 0u;
+        if (__any(rep)) {
+            if (rep) {
+#pragma unroll
+                for (uint32_t j = 0; j < 8; ++j) {
+                    if (j < P) {  // (P is wave-uniform)
+                        const int sh = 32 + 2 * (static_cast<int>(j) - K + 1);   // bit offset of the window in [lo | hi]
+                        const uint32_t f = (sh < 32 ? vkl::alignbit(hi, lo, static_cast<uint32_t>(sh)) : (hi >> (sh - 32))) &
+                                           ((1u << (2 * K)) - 1u);
+                        const uint32_t n = (16u - j + P - 1u) / P;               // positions of the group congruent to j
+                        unsigned long long left = __ballot(true);
+                        bool done = false;
+                        for (uint32_t t = 0; t < 8 && left; ++t) {
+                            const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(f), __builtin_ctzll(left)));
+                            const bool same = !done && f == first;
+                            const unsigned long long eq = __ballot(same);
+                            if (same) {
+                                if (lane == __builtin_ctzll(eq)) add(f, n * static_cast<uint32_t>(__builtin_popcountll(eq)));
+                                done = true;
+                            }
+                            left &= ~eq;
+                        }
+                        if (!done) add(f, n);
+                    }
+                }
+                ok[g] = 0u;
+                ++handled;
+            }
+        }
+    }
+    return handled;
+}
+
+// did at least a third of the wave's groups that had windows go the short way?
+__device__ __forceinline__ bool repeats_dominate(uint32_t handled, const uint32_t ok_in[4]) {
+    const uint32_t had = (ok_in[0] != 0u) + (ok_in[1] != 0u) + (ok_in[2] != 0u) + (ok_in[3] != 0u);
+    const uint32_t sum_h = lane_bcast(wave_inclusive_sum(handled), 63), sum_g = lane_bcast(wave_inclusive_sum(had), 63);
+    return sum_h * 3u >= sum_g && sum_h != 0u;
+}
+
+// Returns whether the piece was low-complexity indeed (the caller stays in this mode while it is).
+template <int K>
+__device__ bool windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok_in[4], uint32_t* hist, uint32_t lds_base,
+                                int lane, uint32_t& probe_addr, unsigned long long& probe_mask) {
+    const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+    constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
+    // the probe for the next piece: the window that ends at position 40 of every lane, however it gets counted
+    {
+        constexpr int Q = 40, o = 30 + 2 * (Q - K + 1), word = o >> 5, sh = o & 31;
         const uint32_t x = sh == 0 ? v[word] : vkl::alignbit(v[word + 1 < 5 ? word + 1 : 4], v[word], static_cast<uint32_t>(sh));
         probe_addr = x & kMask4;
-        probe_mask = __ballot(((ok[P >> 4] >> (2 * (P & 15))) & 1u) != 0u);
+        probe_mask = __ballot(((ok_in[Q >> 4] >> (2 * (Q & 15))) & 1u) != 0u);
     }
     // Homopolymer pieces (poly-A / poly-G tails, the common low-complexity case): every window of a lane is
     // the same k-mer and the lane adds its window count once -- one ds_add per lane and piece instead of 64.
     {
         uint32_t n, base;
-        if (piece_is_homopolymer<K>(ch, C, ok, n, base)) {
+        if (piece_is_homopolymer<K>(ch, C, ok_in, n, base)) {
             if (n != 0u) atomicAdd(&hist[base * (((1u << (2 * K)) - 1u) / 3u)], n);
-            return;
+            return true;
         }
     }
-    vkl::windows<K>(
-        ch, C, ok,
-        [&](uint32_t a4) {  // runs with the counting lanes of one position active
-            unsigned long long left = __ballot(true);
-            bool mine_done = false;
-            for (int it = 0; it < 4 && left; ++it) {
-                const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(a4), __builtin_ctzll(left)));
-                const bool same = !mine_done && a4 == first;
-                const unsigned long long eq = __ballot(same);
-                if (same) {
-                    if (lane == __builtin_ctzll(eq)) atomicAdd(&hist[a4 >> 2], static_cast<uint32_t>(__builtin_popcountll(eq)));
-                    mine_done = true;
-                }
-                left &= ~eq;
-            }
-            if (!mine_done) atomicAdd(&hist[a4 >> 2], 1u);
-        },
-        [] {});
+    uint32_t ok[4] = {ok_in[0], ok_in[1], ok_in[2], ok_in[3]};
+    const uint32_t handled = count_repeats<K>(v, ok, lane, [&](uint32_t f, uint32_t n) {
+        __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(lds_base + 4u * f)),
+                               n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    });
+    uint32_t pa;
+    unsigned long long pm;
+    windows_lds<K>(ch, C, ok, lds_base, pa, pm);
+    return repeats_dominate(handled, ok_in);
 }
 
 // ---- read subsampling (vk_count_sampled_device; vk_lane.h: sample_hash) ------------------------
@@ -690,9 +769,10 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
             uint32_t pa;
             unsigned long long pm;
+            bool still = false;
             if (!hot) windows_lds<K>(ch, C, ok, hist_base, pa, pm);
-            else windows_lds_hot<K>(ch, C, ok, hist, lane, pa, pm);
-            hot = probe_is_hot(pa, pm);
+            else still = windows_lds_hot<K>(ch, C, ok, hist, hist_base, lane, pa, pm);
+            hot = still || probe_is_hot(pa, pm);
         };
         SubWave sw = {0, 0, 0, 0};
         if constexpr (SUB) {
@@ -805,24 +885,23 @@ __device__ __forceinline__ uint32_t lane_now() {
 // The general path of one piece for the dense kernel: exactly vk_count_kernel's piece (all 64 bytes of
 // every lane classified, any number of newlines, bytes >= 0x80, the low-complexity window loop); the
 // mask tables of the rare tiers are worked out on the spot (no LDS left for them).
-struct GeneralPiece {
-    uint32_t d[16];                      // this lane's 64 bytes
-    uint32_t ctx_c, ctx_bad, pph, hot;   // in / out (wave-uniform)
-    uint32_t flags, ph0;                 // bit 0: first piece of the range, bit 1: it starts with a pre-block
+struct GeneralState {
+    uint32_t ctx_c, ctx_bad, pph, hot, tick;   // in / out (wave-uniform)
 };
 
+// (bytes and state travel in registers: through a struct in memory every call cost a round trip to scratch)
 template <int K>
-__device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int lane, uint32_t* hist, uint32_t hist_base) {
-    uint32_t d[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) d[i] = gp->d[i];
-    const bool first = (gp->flags & 1u) != 0u, has_pre = (gp->flags & 2u) != 0u;
-    uint32_t pph = gp->pph;
+__device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 q1, uint4 q2, uint4 q3, GeneralState st,
+                                                                uint32_t flags, uint32_t ph0, int lane, uint32_t* hist,
+                                                                uint32_t hist_base) {
+    const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const bool first = (flags & 1u) != 0u, has_pre = (flags & 2u) != 0u;  // first piece of the range; it starts with a pre-block
+    uint32_t pph = st.pph;
     vkl::LaneBits lb;
     const uint32_t c = __any(vkl::has_non_ascii(d)) ? vkl::classify<false>(d, lb) : vkl::classify<true>(d, lb);
     const uint32_t incl = wave_inclusive_sum(c);
     const uint32_t total = lane_bcast(incl, 63);
-    if (first) pph = has_pre ? gp->ph0 - lane_bcast(c, 0) : 0u;
+    if (first) pph = has_pre ? ph0 - lane_bcast(c, 0) : 0u;
     const uint32_t lph = (pph + incl - c) & 3u;
     vkl::Mask128 seq;
     const bool degenerate = __any(c > 4u);
@@ -833,19 +912,23 @@ __device__ __attribute__((noinline)) void general_piece(GeneralPiece* gp, int la
     else seq = vkl::seq_mask_count(lb.NL, lph);
     uint32_t bad[4], ok[4];
     vkl::bad_mask(lb, seq, bad);
-    const uint32_t badh = wave_prev_lane(bad[3], gp->ctx_bad);
-    const uint32_t ch = wave_prev_lane(lb.C[3], gp->ctx_c);
-    gp->ctx_bad = lane_bcast(bad[3], 63);
-    gp->ctx_c = lane_bcast(lb.C[3], 63);
+    const uint32_t badh = wave_prev_lane(bad[3], st.ctx_bad);
+    const uint32_t ch = wave_prev_lane(lb.C[3], st.ctx_c);
+    st.ctx_bad = lane_bcast(bad[3], 63);
+    st.ctx_c = lane_bcast(lb.C[3], 63);
     vkl::ok_mask<K>(badh, bad, ok);
     if (first && lane == 0 && has_pre) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
     uint32_t pa;
     unsigned long long pm;
-    if (gp->hot == 0u) windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
-    else windows_lds_hot<K>(ch, lb.C, ok, hist, lane, pa, pm);
-    gp->hot = probe_is_hot(pa, pm) ? 1u : 0u;
-    gp->pph = pph + total;
+    bool still = false;
+    if (st.hot == 0u) windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
+    else still = windows_lds_hot<K>(ch, lb.C, ok, hist, hist_base, lane, pa, pm);
+    uint32_t tick = st.tick;
+    st.hot = (still || probe_low_complexity(pa, pm, tick)) ? 1u : 0u;
+    st.tick = tick;
+    st.pph = pph + total;
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+    return st;
 }
 
 template <int K>
@@ -915,6 +998,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         uint32_t pph = 0;     // line phase at the start of the current piece
         uint32_t npend = 0;   // granules waiting in xb[0 .. npend), < 64 between pieces
         bool hot = false;
+        uint32_t tick = 0;    // calls of the low-complexity probe
 
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
@@ -930,7 +1014,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             uint32_t pa;
             unsigned long long pm;
             windows_lds1<K>(ch, C, ok, hist_base, pa, pm);
-            if (probe) hot = probe_is_hot(pa, pm);
+            if (probe) hot = probe_low_complexity(pa, pm, tick);
         };
         auto flush = [&]() __attribute__((always_inline)) {  // the pending granules, before a piece takes the general path
             uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
@@ -970,17 +1054,15 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
                 // classified at once -- would spill the fast path's loop invariants) ----
                 if (npend != 0u) flush();
-                GeneralPiece gp;
-                gp.ctx_c = ctx_c; gp.ctx_bad = ctx_bad; gp.pph = pph; gp.hot = hot ? 1u : 0u;
-                gp.flags = (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u);
-                gp.ph0 = ph0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) gp.d[i] = d[i];
-                general_piece<K>(&gp, static_cast<int>(lane_now()), hist, hist_base);
-                ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_c)));
-                ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.ctx_bad)));
-                pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gp.pph)));
-                hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gp.hot)) != 0;
+                GeneralState gs;
+                gs.ctx_c = ctx_c; gs.ctx_bad = ctx_bad; gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
+                gs = general_piece<K>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u), ph0,
+                                      static_cast<int>(lane_now()), hist, hist_base);
+                ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.ctx_c)));
+                ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.ctx_bad)));
+                pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.pph)));
+                hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gs.hot)) != 0;
+                tick = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.tick)));
                 if (it + 1 < npieces) load_piece(it + 1);
                 continue;
             }
@@ -1317,10 +1399,13 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
         // A piece that saw an overflow makes the next ones try the homopolymer shortcut first: one global
         // atomic per wavefront and piece (the lanes' window counts summed) instead of thousands.
         bool hot = false;
-        auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
+        auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok_) __attribute__((always_inline)) {
+            const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
+            uint32_t okl[4] = {ok_[0], ok_[1], ok_[2], ok_[3]};
+            const uint32_t* ok = okl;
             if (hot) {
                 uint32_t n, b;
-                if (piece_is_homopolymer<K>(ch, C, ok, n, b)) {
+                if (piece_is_homopolymer<K>(ch, C, ok_, n, b)) {
 #pragma unroll
                     for (uint32_t bb = 0; bb < 4; ++bb) {  // (a piece can hold poly-A and poly-T reads: one sum per base)
                         const uint32_t tot = lane_bcast(wave_inclusive_sum(b == bb ? n : 0u), 63);
@@ -1328,9 +1413,13 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                     }
                     return;
                 }
-                hot = false;
+                // tandem repeats of a short period: the lane groups that repeat are counted with a handful of global
+                // atomics per wave (count_repeats), the rest goes through the queues as usual
+                const uint32_t handled = count_repeats<K>(v, okl, lane, [&](uint32_t f, uint32_t cnt) {
+                    atomicAdd(&hist_s[pair_reverse(f, K)], cnt);
+                });
+                hot = repeats_dominate(handled, ok_);
             }
-            const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // bit 4j of `both` / `one`: both / exactly one of the windows ending at 16g + 2j, 16g + 2j + 1 count

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-config4"
+BENCH="python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-e2e --no-config4"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 BENCHS="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCHS > $OUT/bench_fetch.json 2> $OUT/fetch.err

@@ -127,8 +127,10 @@ int vk_fastq_to_image_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* o
  * text does not fit out_caps[i] gets VK_GZ_OVERFLOW and no text; where the whole file was decoded before the
  * slot was looked at (files of 512 KiB and more) out_lengths[i] then holds the size a second call needs
  * (> out_caps[i]), otherwise the bytes that fitted.
- * Integrity: structure and every member's ISIZE are checked; the trailer's CRC-32 is verified (on the GPU)
- * for files that consist of one member, which is what the reference's pipeline writes. */
+ * Integrity: structure and every member's ISIZE are checked, and every member's CRC-32 word is verified (on the
+ * GPU) against the stretch of text the member inflated to (VK_GZ_BAD_CRC) -- as zlib's gzread, which dsk reads
+ * through, does; only a file with more than 62 members inside one 128 KiB stretch of compressed bytes goes
+ * unchecked. */
 int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets, const uint64_t* gz_lengths,
                       uint32_t nfiles, void* d_out, const uint64_t* out_offsets, const uint64_t* out_caps,
                       uint64_t* out_lengths, uint32_t* status);

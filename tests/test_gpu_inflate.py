@@ -279,10 +279,11 @@ def test_inflate_verifies_the_crc_of_single_member_files(engines):
         got, status, _, _ = run(eng, [bytes(f)])
         assert status[0] == _capi.VK_GZ_BAD_CRC, status
         assert len(got[0]) == len(want) and got[0] != text
-    # several members: sizes are checked, check words are not (documented in include/vkimg.h)
-    two = with_crc(gz(small), 5) + gz(small[:1000])
-    got, status, _, _ = run(eng, [two], caps=[len(small) + 1000])
-    assert status[0] == 0 and got[0] == small + small[:1000]
+    # several members: every member's check word is verified against its own stretch of the text
+    two_bad = with_crc(gz(small), 5) + gz(small[:1000])
+    two_good = gz(small) + gz(b"") + gz(small[:1000])
+    got, status, _, _ = run(eng, [two_bad, two_good], caps=[len(small) + 1000] * 2)
+    assert status.tolist() == [_capi.VK_GZ_BAD_CRC, 0] and got[0] == got[1] == small + small[:1000]
 
 
 def test_inflate_chunk_sizes_and_false_block_starts(monkeypatch):
@@ -366,7 +367,7 @@ def test_many_member_files_are_sized_up_front_and_inflated_once(engines, tmp_pat
             for n, o, ln in zip(names, offs, lens):
                 assert bytes(text[int(o):int(o) + int(ln)]) == want[n], n
             if names[0].startswith("bgzf"):
-                assert calls == [3], calls              # one inflate call, nothing inflated twice
+                assert len(calls) == 1 and calls[0] > 1000, calls   # ONE inflate call (a job per BGZF member), nothing inflated twice
             elif names[0] == "concat.fq.gz":
                 assert calls == [1, 1], calls           # once more, into a slot of the size the first pass reported
             else:
@@ -394,3 +395,54 @@ def test_a_truncated_gzip_file_cannot_reserve_gigabytes(engines, tmp_path):
     dev, offs, lens = eng.upload_staged(st)
     assert int(lens[0]) == 0 and int(lens[1]) == len(a)
     assert bytes(dev.cpu().numpy()[int(offs[1]):int(offs[1]) + len(a)]) == a
+
+
+def test_inflate_verifies_every_member_of_many_member_files(engines, tmp_path):
+    """BGZF and concatenated files: a wrong check word in ONE member in the middle -- sizes all right, text all
+    right -- is VK_GZ_BAD_CRC.  Through the C ABI (a small BGZF file on the one-wavefront path, a large
+    concatenation on the chunked path with members crossing chunk borders) and through the file route, where a
+    BGZF file is inflated member by member."""
+    eng = engines(7)
+    small = synth.sample_fastq(41, 2500, 150).tobytes()                     # 0.8 MB of text
+    large = synth.sample_fastq(42, 120000, 150, dist=1).tobytes()           # 38 MB
+
+    def flip_member_crc(blob, which):
+        """The CRC-32 word of member `which` (0-based) of a BGZF file, plus one."""
+        pos = 0
+        for _ in range(which):
+            pos += (blob[pos + 16] | (blob[pos + 17] << 8)) + 1
+        end = pos + (blob[pos + 16] | (blob[pos + 17] << 8)) + 1
+        word = struct.unpack("<I", blob[end - 8:end - 4])[0]
+        return blob[:end - 8] + struct.pack("<I", (word + 1) & 0xFFFFFFFF) + blob[end - 4:]
+
+    def members(blob):
+        return blob.count(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC")
+
+    good = bgzf(small, block=20000)
+    nm = members(good)
+    assert 30 < nm <= 62
+    files = [good, flip_member_crc(good, nm // 2), flip_member_crc(good, nm - 1)]      # (the last one: the empty end marker)
+    texts, bad = [small] * 3, [False, True, True]
+    cat = [gz(large[i:i + 2_500_000], 1 + (i // 2_500_000) % 9) for i in range(0, len(large), 2_500_000)]
+    files.append(b"".join(cat))
+    j = len(cat) // 2
+    word = struct.unpack("<I", cat[j][-8:-4])[0]
+    cat[j] = cat[j][:-8] + struct.pack("<I", word ^ 0x10) + cat[j][-4:]
+    files.append(b"".join(cat))
+    texts += [large, large]
+    bad += [False, True]
+    got, status, _, _ = run(eng, files, caps=[len(t) for t in texts])
+    assert [bool(x) for x in status.tolist()] == bad, status.tolist()
+    assert all(x in (0, _capi.VK_GZ_BAD_CRC) for x in status.tolist())
+    assert all(g == t for g, t in zip(got, texts))
+    # the file route: thousands of members, each inflated and checked as a file of its own
+    for block in (30000, 65280):
+        blob = bgzf(large, block=block)
+        n = members(blob)
+        names = []
+        for tag, data in (("ok", blob), ("mid", flip_member_crc(blob, n // 2)), ("end", flip_member_crc(blob, n - 1))):
+            names.append(tmp_path / f"{tag}_{block}.fq.gz")
+            names[-1].write_bytes(data)
+        dev, offs, lens = eng.upload_files(names)
+        assert [int(x) for x in lens] == [len(large), 0, 0]
+        assert bytes(dev.cpu().numpy()[int(offs[0]):int(offs[0]) + len(large)]) == large

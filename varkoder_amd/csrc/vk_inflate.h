@@ -418,6 +418,7 @@ struct GzChunk {
 };
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
 constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
+constexpr uint32_t kGzMemRec = 62;         // member trailers a wavefront records (end of the member's text in ITS output, CRC-32 word); a file with more in one chunk goes unchecked
 
 #ifdef VK_GZ_STAMPS
 // Diagnostic build only (tools/gz_stamps.py): per-chunk clocks of the chunk decoder, in a debug buffer that
@@ -743,7 +744,7 @@ template <bool SYM>
 __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
                         uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
                         uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
-                        uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc) {
+                        uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc, uint2* memrec) {
     const int lane = threadIdx.x & 63;
     const uint64_t nbits = nbytes * 8;
 #ifdef VK_GZ_STAMPS
@@ -928,9 +929,10 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                                (static_cast<uint32_t>(in[b + 7]) << 24);
         if (!window_open && isize != static_cast<uint32_t>(opos - member_text0)) { st |= kGzBadSize; break; }  // (a member that began in an earlier chunk is checked by the host: sum of the chunks)
         isize_sum += isize;
-        ++members;
         last_crc = in[b] | (static_cast<uint32_t>(in[b + 1]) << 8) | (static_cast<uint32_t>(in[b + 2]) << 16) |
                    (static_cast<uint32_t>(in[b + 3]) << 24);
+        if (memrec != nullptr && members < kGzMemRec && lane == 0) memrec[members] = make_uint2(static_cast<uint32_t>(opos), last_crc);
+        ++members;
         pos = (b + 8) * 8;
         if (SYM) {  // the starts found inside what this chunk decoded (none, or false ones) are behind us
             while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;
@@ -957,14 +959,14 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
                                                          const GzJob* __restrict__ jobs, uint32_t njobs,
                                                          unsigned long long* __restrict__ out_len,
                                                          uint32_t* __restrict__ status, uint32_t* __restrict__ members,
-                                                         uint32_t* __restrict__ crc) {
+                                                         uint32_t* __restrict__ crc, uint2* __restrict__ memrec) {
     __shared__ GzLds L;
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
     uint64_t n = 0, endbit = 0;
     uint32_t st = 0, next = 0, isum = 0, nm = 0, cr = 0;
     gz_wave<false>(L, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
-                   nullptr, 0, 0, n, st, next, endbit, isum, nm, cr);
+                   nullptr, 0, 0, n, st, next, endbit, isum, nm, cr, memrec + static_cast<size_t>(job) * kGzMemRec);
     if ((threadIdx.x & 63) == 0) {
         out_len[job] = n;
         status[job] = st;
@@ -1130,7 +1132,8 @@ __global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __rest
                                                          const uint64_t* __restrict__ starts,
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
                                                          uint32_t* __restrict__ next, uint32_t* __restrict__ isize_sum,
-                                                         uint32_t* __restrict__ members, uint32_t* __restrict__ crc) {
+                                                         uint32_t* __restrict__ members, uint32_t* __restrict__ crc,
+                                                         uint2* __restrict__ memrec) {
     __shared__ GzLds L;
     const uint32_t c = blockIdx.x;
     if (c >= nchunks_total) return;
@@ -1143,7 +1146,7 @@ __global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __rest
         st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
     } else {
         gz_wave<true>(L, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
-                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr);
+                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr, memrec + static_cast<size_t>(c) * kGzMemRec);
     }
     if ((threadIdx.x & 63) == 0) {
         out_len[c] = n;

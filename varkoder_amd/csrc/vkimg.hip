@@ -619,8 +619,25 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
     const uint8_t* gz = static_cast<const uint8_t*>(d_gz);
     uint8_t* out = static_cast<uint8_t*>(d_out);
     std::vector<uint32_t> direct;  // files that go through the one-wavefront-per-file kernel
-    std::vector<GzCrcJob> crc_jobs;        // single-member files: their text's CRC-32 is checked against the trailer's
+    std::vector<GzCrcJob> crc_jobs;        // one per gzip member with text: its CRC-32 is checked against the member's trailer
     std::vector<uint32_t> crc_file, crc_want;
+    std::vector<std::pair<uint64_t, uint32_t>> members;  // of the file in hand: (end of the member's text in the file's text, CRC-32 word)
+    // every member of file i (text at text_off, text_len bytes; `members` in order) gets a check of its own;
+    // an empty member's check word must be that of no bytes
+    auto add_member_checks = [&](uint32_t i, uint64_t text_off, uint64_t text_len) {
+        uint64_t from = 0;
+        for (const auto& mb : members) {
+            if (mb.first < from || mb.first > text_len) return;  // (cannot happen for a file whose sizes added up)
+            if (mb.first == from) {
+                if (mb.second != 0u) status[i] |= VK_GZ_BAD_CRC;
+            } else {
+                crc_jobs.push_back(GzCrcJob{text_off + from, mb.first - from, 0, 0});
+                crc_file.push_back(i);
+                crc_want.push_back(mb.second);
+            }
+            from = mb.first;
+        }
+    };
 
     // ---- large files: many wavefronts per file (vk_inflate.h, "the chunked path") ------------------
     std::vector<uint32_t> big;
@@ -663,7 +680,8 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         // metadata: chunks | starts u64 | len u64 | status u32 | next u32 | isize u32
         const size_t o_chunks = 0, o_starts = o_chunks + nc * sizeof(GzChunk), o_len = o_starts + nc * 8ull,
                      o_st = o_len + nc * 8ull, o_next = o_st + nc * 4ull, o_is = o_next + nc * 4ull, o_nm = o_is + nc * 4ull,
-                     o_cr = o_nm + nc * 4ull, meta_b = o_cr + nc * 4ull;
+                     o_cr = o_nm + nc * 4ull, o_rec = (o_cr + nc * 4ull + 15) / 16 * 16,
+                     meta_b = o_rec + static_cast<size_t>(nc) * kGzMemRec * sizeof(uint2);
         int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzmeta), &ctx->gzmeta_cap, meta_b + 256);
         if (rc) return rc;
         rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzsym), &ctx->gzsym_cap, sym_total * 2 + 256);
@@ -677,15 +695,18 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         uint32_t* d_is = reinterpret_cast<uint32_t*>(m + o_is);
         uint32_t* d_nm = reinterpret_cast<uint32_t*>(m + o_nm);
         uint32_t* d_cr = reinterpret_cast<uint32_t*>(m + o_cr);
+        uint2* d_rec = reinterpret_cast<uint2*>(m + o_rec);
         uint16_t* d_sym = reinterpret_cast<uint16_t*>(ctx->d_gzsym);
         VK_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), nc * sizeof(GzChunk), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(vk_gzfind_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_chunks, nc, d_starts);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(vk_gzchunk_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_sym, d_chunks, nc, d_starts, d_len,
-                           d_st, d_next, d_is, d_nm, d_cr);
+                           d_st, d_next, d_is, d_nm, d_cr, d_rec);
         VK_HIP(ctx, hipGetLastError());
         std::vector<unsigned long long> h_len(nc);
         std::vector<uint32_t> h_st(nc), h_next(nc), h_is(nc), h_nm(nc), h_cr(nc);
+        std::vector<uint2> h_rec(static_cast<size_t>(nc) * kGzMemRec);
+        VK_HIP(ctx, hipMemcpyAsync(h_rec.data(), d_rec, h_rec.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, nc * 8ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_next.data(), d_next, nc * 4ull, hipMemcpyDeviceToHost, ctx->stream));
@@ -703,9 +724,16 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             uint32_t isum = 0, nmem = 0, lastcrc = 0;
             bool ok = true;
             uint32_t c = chunk0[b];
+            members.clear();
+            bool members_known = true;   // every trailer's (end of text, check word) on record?
             for (;;) {
                 if (h_st[c] != 0) { ok = false; break; }
                 items.push_back(GzItem{chunks[c].out_off, h_len[c], out_offsets[i] + total});
+                if (h_nm[c] > kGzMemRec) members_known = false;
+                for (uint32_t r = 0; r < h_nm[c] && r < kGzMemRec; ++r) {
+                    const uint2 rec = h_rec[static_cast<size_t>(c) * kGzMemRec + r];
+                    members.push_back({total + rec.x, rec.y});
+                }
                 total += h_len[c];
                 isum += h_is[c];
                 if (h_nm[c]) {
@@ -733,7 +761,8 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             count.push_back(static_cast<uint32_t>(items.size() - mark));
             okfile.push_back(i);
             out_lengths[i] = total;
-            if (nmem == 1) crc_jobs.push_back(GzCrcJob{out_offsets[i], total, 0, 0}), crc_file.push_back(i), crc_want.push_back(lastcrc);
+            (void)lastcrc;
+            if (members_known && members.size() == nmem) add_member_checks(i, out_offsets[i], total);
         }
         if (!okfile.empty()) {
             const uint32_t ni = static_cast<uint32_t>(items.size()), nf = static_cast<uint32_t>(okfile.size());
@@ -770,7 +799,8 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         const uint32_t nd = static_cast<uint32_t>(direct.size());
         const size_t jobs_b = static_cast<size_t>(nd) * sizeof(GzJob), len_b = static_cast<size_t>(nd) * 8,
                      st_b = static_cast<size_t>(nd) * 4;
-        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, jobs_b + len_b + 3 * st_b);
+        const size_t rec_o = (jobs_b + len_b + 3 * st_b + 15) / 16 * 16, rec_b = static_cast<size_t>(nd) * kGzMemRec * sizeof(uint2);
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_gzjobs), &ctx->gzjobs_cap, rec_o + rec_b);
         if (rc) return rc;
         std::vector<GzJob> jobs(nd);
         for (uint32_t j = 0; j < nd; ++j) {
@@ -783,10 +813,13 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         uint32_t* d_nm = d_st + nd;
         uint32_t* d_cr = d_nm + nd;
         VK_HIP(ctx, hipMemcpyAsync(d_jobs, jobs.data(), jobs_b, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(vk_inflate_kernel, dim3(nd), dim3(64), 0, ctx->stream, gz, out, d_jobs, nd, d_len, d_st, d_nm, d_cr);
+        uint2* d_rec = reinterpret_cast<uint2*>(ctx->d_gzjobs + rec_o);
+        hipLaunchKernelGGL(vk_inflate_kernel, dim3(nd), dim3(64), 0, ctx->stream, gz, out, d_jobs, nd, d_len, d_st, d_nm, d_cr, d_rec);
         VK_HIP(ctx, hipGetLastError());
         std::vector<unsigned long long> h_len(nd);
         std::vector<uint32_t> h_st(3 * static_cast<size_t>(nd));
+        std::vector<uint2> h_rec(static_cast<size_t>(nd) * kGzMemRec);
+        VK_HIP(ctx, hipMemcpyAsync(h_rec.data(), d_rec, rec_b, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_len.data(), d_len, len_b, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipMemcpyAsync(h_st.data(), d_st, 3 * st_b, hipMemcpyDeviceToHost, ctx->stream));
         VK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also keeps `jobs` alive until the copy has read it)
@@ -794,11 +827,15 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             const uint32_t i = direct[j];
             out_lengths[i] = h_len[j];
             status[i] = h_st[j];
-            if (h_st[j] == 0 && h_st[nd + j] == 1)
-                crc_jobs.push_back(GzCrcJob{out_offsets[i], h_len[j], 0, 0}), crc_file.push_back(i), crc_want.push_back(h_st[2 * nd + j]);
+            const uint32_t nm = h_st[nd + j];
+            if (h_st[j] == 0 && nm >= 1 && nm <= kGzMemRec && h_len[j] < (1ull << 32)) {
+                members.clear();
+                for (uint32_t r = 0; r < nm; ++r) members.push_back({h_rec[static_cast<size_t>(j) * kGzMemRec + r].x, h_rec[static_cast<size_t>(j) * kGzMemRec + r].y});
+                add_member_checks(i, out_offsets[i], h_len[j]);
+            }
         }
     }
-    // the check word of every single-member file against the CRC-32 of the text it inflated to
+    // the check word of every member against the CRC-32 of the text it inflated to
     if (!crc_jobs.empty()) {
         std::vector<uint32_t> got;
         int rc = gz_text_crc(ctx, out, crc_jobs, got);

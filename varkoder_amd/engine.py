@@ -18,15 +18,19 @@ def _torch():
     return torch
 
 
-def bgzf_text_size(buf):
-    """Text bytes of a BGZF file (what `bgzip` and BBTools-through-bgzip write: gzip members of at most
-    64 KiB, each with its own size in a 'BC' extra field), summed over the members' ISIZE words by hopping
-    from block header to block header -- no inflating.  None when `buf` is not BGZF from end to end.  The
-    last member of such a file is an empty one (ISIZE 0), so the size word that ends the FILE says nothing
-    about the text."""
+def bgzf_members(buf):
+    """The members of a BGZF file (what `bgzip` and BBTools-through-bgzip write: gzip members of at most
+    64 KiB, each with its own size in a 'BC' extra field), found by hopping from block header to block header
+    -- no inflating: (offsets, compressed sizes, text sizes) as uint64 arrays, or None when `buf` is not BGZF
+    from end to end.  The last member of such a file is an empty one (ISIZE 0), so the size word that ends
+    the FILE says nothing about the text; and since no member refers to another, every member can be inflated
+    by a wavefront of its own."""
     n = len(buf)
-    pos = total = 0
+    if n == 0:
+        return None
     mv = memoryview(buf)
+    offs, sizes, texts = [], [], []
+    pos = 0
     while pos < n:
         if pos + 18 > n:
             return None
@@ -36,9 +40,17 @@ def bgzf_text_size(buf):
         size = (h[16] | (h[17] << 8)) + 1
         if size < 26 or pos + size > n:
             return None
-        total += int.from_bytes(bytes(mv[pos + size - 4:pos + size]), "little")
+        offs.append(pos)
+        sizes.append(size)
+        texts.append(int.from_bytes(bytes(mv[pos + size - 4:pos + size]), "little"))
         pos += size
-    return total if n else None
+    return (np.array(offs, dtype=np.uint64), np.array(sizes, dtype=np.uint64), np.array(texts, dtype=np.uint64))
+
+
+def bgzf_text_size(buf):
+    """Text bytes of a BGZF file (the sum of its members' ISIZE words), None when `buf` is not BGZF."""
+    m = bgzf_members(buf)
+    return None if m is None else int(m[2].sum())
 
 
 # A gzip file's text slot in HBM is reserved before anything is inflated.  The size word that ends the file
@@ -196,6 +208,7 @@ class ImageEngine:
             pinned = torch.empty(max(stage_total, 1 << 20), dtype=torch.uint8, pin_memory=True)
             slots[slot] = pinned
         host = pinned.numpy()
+        bgzf = {}    # file index -> member table of a BGZF file
 
         def fill(i):
             o, nb = int(src[i]), int(disk[i])
@@ -214,9 +227,10 @@ class ImageEngine:
                 elif is_gz[i] and nb >= 28 and host[o + 3] & 4:
                     # many-member files (BGZF): the text size is the sum over the members, found by walking
                     # the block headers -- not the last member's size word (0 for BGZF's empty end marker)
-                    t = bgzf_text_size(host[o:o + nb])
-                    if t is not None:
-                        caps[i] = t
+                    m = bgzf_members(host[o:o + nb])
+                    if m is not None:
+                        caps[i] = int(m[2].sum())
+                        bgzf[i] = m
             host[o + nb:(o + nb + 15) // 16 * 16] = 0
         list(mapper(fill, range(n)))
         # text layout in HBM: the plain region as staged, then the slots of the gzip files
@@ -227,7 +241,7 @@ class ImageEngine:
         text_total = pos + 16
         return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
-                "paths": [str(p) for p in paths]}
+                "paths": [str(p) for p in paths], "bgzf": bgzf}
 
     def upload_staged(self, staged, timings=None):
         """Device half: one H2D DMA of the plain text, one of the compressed files, and the gzip files
@@ -248,8 +262,32 @@ class ImageEngine:
             gzdev = pinned[plain_total:stage_total]
             import time
             ti = time.perf_counter()
-            got, st = self.inflate(gzdev, staged["src"][gi] - np.uint64(plain_total), staged["disk"][gi], dev,
-                                   offs[gi], staged["caps"][gi])
+            # A BGZF file goes in as its members: no member refers to another, so each is a gzip file of its
+            # own -- a wavefront per member instead of one per file, its size and CRC-32 checked like any file's.
+            table = staged.get("bgzf") or {}
+            go, gl, oo, oc, owner = [], [], [], [], []
+            for j, i in enumerate(gi):
+                base = staged["src"][i] - np.uint64(plain_total)
+                if int(i) in table:
+                    mo, ms, mt = table[int(i)]
+                    ends = np.cumsum(mt)
+                    go.append(base + mo)
+                    gl.append(ms)
+                    oo.append(offs[i] + ends - mt)
+                    oc.append(mt)
+                    owner.append(np.full(mo.size, j, dtype=np.int64))
+                else:
+                    go.append(np.array([base], dtype=np.uint64))
+                    gl.append(staged["disk"][i:i + 1])
+                    oo.append(offs[i:i + 1])
+                    oc.append(staged["caps"][i:i + 1])
+                    owner.append(np.array([j], dtype=np.int64))
+            owner = np.concatenate(owner)
+            g1, s1 = self.inflate(gzdev, np.concatenate(go), np.concatenate(gl), dev, np.concatenate(oo), np.concatenate(oc))
+            got = np.zeros(gi.size, dtype=np.uint64)
+            st = np.zeros(gi.size, dtype=np.uint32)
+            np.add.at(got, owner, g1)
+            np.bitwise_or.at(st, owner, s1)
             if timings is not None:
                 timings["inflate_s"] = timings.get("inflate_s", 0.0) + time.perf_counter() - ti
             # More text than the slot held (several members and only the last one's size word known, or a

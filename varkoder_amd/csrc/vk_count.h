@@ -1173,9 +1173,10 @@ constexpr uint32_t kLdsScratch = kLdsUsed + kWaves * kQueues * 4; // u64 [kWaves
 constexpr uint32_t kLdsBelow = kLdsScratch + kWaves * 64;         // uint4 [66]
 constexpr uint32_t kLdsAbove = kLdsBelow + 66 * 16;               // uint4 [66]
 constexpr uint32_t kLdsQueues = 8192;                             // u16 [kWaves][16][128]
-constexpr uint32_t kLdsBucketBytes = kLdsQueues + kWaves * kQueues * kQueueBytes;
+constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // uint2 [kWaves][64]: (codes, OK) of lane groups on their way to the append stage
+constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 static_assert(kLdsAbove + 66 * 16 <= kLdsQueues, "LDS layout");
-static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");
+static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");  // = exactly 160 KiB
 
 // Raw window field (first base least significant) of the window of type t (0: ends at p, 1: ends at
 // p + 1) of a pair entry e of bucket q:  t = 0: rest | q << LB;  t = 1: rest without its first base,
@@ -1398,11 +1399,50 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
         // Low-complexity input sends every pair to ONE queue, which overflows into per-pair global atomics.
         // A piece that saw an overflow makes the next ones try the homopolymer shortcut first: one global
         // atomic per wavefront and piece (the lanes' window counts summed) instead of thousands.
+        // The append stage of one lane group (16 positions): lo = codes of the 16 positions before it, hi = its own,
+        // okg = its OK string.
         bool hot = false;
+        uint32_t xpend = 0, xctx = 0;  // dense stage: groups waiting in the exchange buffer, codes of the last group appended
+        auto append_group = [&](uint32_t lo, uint32_t hi, uint32_t okg) __attribute__((always_inline)) {
+            // bit 4j of `both` / `one`: both / exactly one of the windows ending at 2j, 2j + 1 count
+            const uint32_t both = okg & (okg >> 2) & 0x11111111u;
+            const uint32_t one = (okg ^ (okg >> 2)) & 0x11111111u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t x[4], f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = 8 * h + 2 * j;             // windows ending at p and p + 1
+                    const int o = 32 + 2 * (p - K + 1);      // bit offset of base p-K+1 in [lo | hi]
+                    x[j] = o >= 32 ? (hi >> (o - 32)) : vkl::alignbit(hi, lo, static_cast<uint32_t>(o));
+                    f[j] = both & (1u << (16 * h + 4 * j));
+                }
+                const uint32_t full = append4(x, f);
+                if (__any(full != 0u)) hot = true;
+                if (full) {  // rare: the queue was full, count the pair directly
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (full & (1u << j)) {
+                            count_direct(x[j]);
+                            count_direct(x[j] >> 2);
+                        }
+                }
+            }
+            // singles: at most a few per lane and piece
+            uint32_t rem = one;
+            while (__any(rem != 0u)) {
+                if (rem != 0u) {
+                    const uint32_t b = vkl::ffbl(rem);                 // 4j
+                    rem &= rem - 1u;
+                    const uint32_t second = ((okg >> b) & 1u) ^ 1u;    // 0: the window ending at p counts, 1: at p + 1
+                    const uint32_t o = 32u + b + 2u * second - 2u * (K - 1);   // bit offset of the window's first base in [lo | hi]
+                    single(o < 32u ? vkl::alignbit(hi, lo, o) : (hi >> (o - 32u)));
+                }
+            }
+        };
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok_) __attribute__((always_inline)) {
             const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
             uint32_t okl[4] = {ok_[0], ok_[1], ok_[2], ok_[3]};
-            const uint32_t* ok = okl;
             if (hot) {
                 uint32_t n, b;
                 if (piece_is_homopolymer<K>(ch, C, ok_, n, b)) {
@@ -1411,66 +1451,61 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                         const uint32_t tot = lane_bcast(wave_inclusive_sum(b == bb ? n : 0u), 63);
                         if (tot != 0u && lane == 0) atomicAdd(&hist_s[pair_reverse(bb * (FMASK / 3u), K)], tot);
                     }
-                    return;
+                    okl[0] = 0u; okl[1] = 0u; okl[2] = 0u; okl[3] = 0u;   // nothing left to append (the dense stage still passes the context on)
+                } else {
+                    // tandem repeats of a short period: the lane groups that repeat are counted with a handful of global
+                    // atomics per wave (count_repeats), the rest goes through the queues as usual
+                    const uint32_t handled = count_repeats<K>(v, okl, lane, [&](uint32_t f, uint32_t cnt) {
+                        atomicAdd(&hist_s[pair_reverse(f, K)], cnt);
+                    });
+                    hot = repeats_dominate(handled, ok_);
                 }
-                // tandem repeats of a short period: the lane groups that repeat are counted with a handful of global
-                // atomics per wave (count_repeats), the rest goes through the queues as usual
-                const uint32_t handled = count_repeats<K>(v, okl, lane, [&](uint32_t f, uint32_t cnt) {
-                    atomicAdd(&hist_s[pair_reverse(f, K)], cnt);
-                });
-                hot = repeats_dominate(handled, ok_);
             }
+            if constexpr (SUB) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // bit 4j of `both` / `one`: both / exactly one of the windows ending at 16g + 2j, 16g + 2j + 1 count
-                const uint32_t both = ok[g] & (ok[g] >> 2) & 0x11111111u;
-                const uint32_t one = (ok[g] ^ (ok[g] >> 2)) & 0x11111111u;
-                if (__any((both | one) != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        uint32_t x[4], f[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int p = 16 * g + 8 * h + 2 * j;    // windows ending at p and p + 1
-                            const int o = 32 + 2 * (p - K + 1);      // bit offset of base p-K+1 in [ch | C]
-                            const int word = o >> 5, sh = o & 31;
-                            if (sh == 0) x[j] = v[word];
-                            else if (word == 4) x[j] = v[4] >> sh;   // the last pair ends exactly at bit 160
-                            else x[j] = vkl::alignbit(v[word + 1], v[word], static_cast<uint32_t>(sh));
-                            f[j] = both & (1u << (16 * h + 4 * j));
-                        }
-                        const uint32_t full = append4(x, f);
-                        if (__any(full != 0u)) hot = true;
-                        if (full) {  // rare: the queue was full, count the pair directly
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (full & (1u << j)) {
-                                    count_direct(x[j]);
-                                    count_direct(x[j] >> 2);
-                                }
-                        }
+                for (int g = 0; g < 4; ++g) {
+                    if (__any(okl[g] != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common
+                        append_group(v[g], v[g + 1], okl[g]);
+                        if (g == 1) maybe_drain(kDrainAt);  // inside a piece only a queue that is filling up fast is drained (skewed bases)
                     }
-                    // singles: at most a few per lane and piece
-                    uint32_t rem = one;
-                    while (__any(rem != 0u)) {
-                        if (rem != 0u) {
-                            const uint32_t b = vkl::ffbl(rem);                 // 4j
-                            rem &= rem - 1u;
-                            const uint32_t second = ((ok[g] >> b) & 1u) ^ 1u;  // 0: the window ending at p counts, 1: at p + 1
-                            // bit offset of the window's first base, relative to v[g]: p = 8g.. in this dword
-                            const uint32_t o = 32u + b + 2u * second - 2u * (K - 1);
-                            const uint32_t lo = o < 32u ? v[g] : v[g + 1];
-                            const uint32_t hi = o < 32u ? v[g + 1] : (g + 2 < 5 ? v[g + 2 < 5 ? g + 2 : 4] : 0u);  // (g = 3: the field ends with v[4])
-                            single(vkl::alignbit(hi, lo, o & 31u));
-                        }
-                    }
-                    // inside a piece only a queue that is filling up fast is drained (skewed bases): one check, half way
-#ifdef VK_BUCKET_DRAIN_EVERY_GROUP
-                    maybe_drain(kDrainAt);
-#else
-                    if (g == 1) maybe_drain(kDrainAt);
-#endif
                 }
+            } else {
+                // The append stage runs on lane groups that HAVE windows (45 % of them in a FASTQ of 150-base reads):
+                // (codes, OK) of those go through a 64-slot exchange buffer in file order, one group per lane and
+                // round.  A group's K - 1 bases of context are the codes of the group before it in the stream:
+                // a group without windows of its own is sent along when the next one's windows reach back into it
+                // (and the piece's very last group always: the next piece cannot be asked yet).
+                constexpr uint32_t kBack = (1u << (2 * (K - 1))) - 1u;  // OK bits of the windows that need bases of the group before
+                const uint32_t nb0 = (okl[0] & kBack) != 0u, nb1 = (okl[1] & kBack) != 0u, nb2 = (okl[2] & kBack) != 0u,
+                               nb3 = (okl[3] & kBack) != 0u;
+                const uint32_t nbn = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(1, static_cast<int>(nb0), 0x130, 0xF, 0xF, false));  // wave_shl:1: lane + 1's, lane 63 gets 1
+                const uint32_t lv[4] = {(okl[0] != 0u) | nb1, (okl[1] != 0u) | nb2, (okl[2] != 0u) | nb3, (okl[3] != 0u) | nbn};
+                const uint32_t n = lv[0] + lv[1] + lv[2] + lv[3];
+                const uint32_t incl = wave_inclusive_sum(n);
+                const uint32_t tot = xpend + lane_bcast(incl, 63);
+                uint32_t at = xpend + incl - n;
+                uint32_t wp[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    wp[g] = lv[g] ? at : 0xFFFFFFC0u;
+                    at += lv[g];
+                }
+                uint2* const xg = reinterpret_cast<uint2*>(ldsb + kLdsXchg) + static_cast<uint32_t>(wave) * 64u;
+                const uint32_t rounds = tot >> 6;
+                for (uint32_t r = 0; r <= rounds; ++r) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if ((wp[g] >> 6) == r) xg[wp[g] & 63u] = make_uint2(C[g], okl[g]);
+                    if (r == rounds) break;  // what is left (< 64 groups) waits in the buffer for the next piece
+                    uint32_t lz = static_cast<uint32_t>(lane);
+                    asm volatile("" : "+v"(lz));
+                    const uint2 e = xg[lz];
+                    const uint32_t lo = wave_prev_lane(e.x, xctx);
+                    xctx = lane_bcast(e.x, 63);
+                    append_group(lo, e.x, e.y);
+                    maybe_drain(kDrainAt);
+                }
+                xpend = tot & 63u;
             }
         };
         SubWave sw = {0, 0, 0, 0};
@@ -1481,6 +1516,16 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
         wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
                                                 piece_start, ph_start, ph_end, sw);
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
+        if constexpr (!SUB) {
+            if (xpend != 0u) {  // the groups still waiting in the exchange buffer
+                const uint2* const xg = reinterpret_cast<const uint2*>(ldsb + kLdsXchg) + static_cast<uint32_t>(wave) * 64u;
+                uint2 e = make_uint2(0u, 0u);
+                if (static_cast<uint32_t>(lane) < xpend) e = xg[lane];
+                const uint32_t lo = wave_prev_lane(e.x, xctx);
+                append_group(lo, e.x, e.y);
+                xpend = 0u;
+            }
+        }
         if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
         if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
         // the end of the range: full blocks to the arena, the rest of every queue counted directly, runs closed

@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--e2e-reads", type=int, default=560_000, help="reads per file of the end-to-end measurement "
                     "(256 x 560k x 150 bp = 21.5 Gbases: about a second per pass)")
     ap.add_argument("--e2e-passes", type=int, default=3)
+    ap.add_argument("--e2e-files-per-rank", type=int, default=24, help="files of the end-to-end leg at N > 1 (per rank)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this "
                     "process may use: physical cores, capped by affinity and the cgroup's CPU quota)")
@@ -269,6 +270,64 @@ def end_to_end(eng, args):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
+    """The end-to-end leg at N > 1: every rank runs the file pipeline on its OWN set of files (written by the
+    rank, page cache warm) at the same time -- what a node-level run of `torchrun -m varkoder_amd image` does
+    to the host: `world` staging pools reading the page cache and `world` H2D streams at once.  Passes start
+    at a barrier; a pass's aggregate is all ranks' bases over the slowest rank's time; the median pass is
+    quoted, with every rank's time.  Fewer and smaller than the N=1 leg (the node's disk and page cache hold
+    every rank's files).  Plain text only."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+
+    import torch
+    from varkoder_amd import pipeline
+    from varkoder_amd.shard import usable_cores
+    nfiles, reads = args.e2e_files_per_rank, args.e2e_reads
+    threads = max(1, usable_cores() // world)
+    tmp = Path(tempfile.mkdtemp(prefix="vk_e2e_r%d_" % rank))
+    res = None
+    try:
+        fq, offs, lens = eng.synth((2 << 20) + rank * nfiles, nfiles, reads, args.readlen, dist=args.dist)
+        host = fq.cpu().numpy()
+        del fq
+        torch.cuda.empty_cache()
+        kb = reads * args.readlen // 1000
+        files = [tmp / f"r{rank}s{i:04d}@{kb:08d}K.fq" for i in range(nfiles)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: host[int(offs[i]):int(offs[i]) + int(lens[i])].tofile(files[i]), range(nfiles)))
+        del host
+        pipeline.fastqs_to_images(files, tmp / "warm", k=args.k, mapping_code=args.mapping, io_threads=threads, engine=eng)
+        shutil.rmtree(tmp / "warm", ignore_errors=True)
+        per_pass = []
+        for rep in range(max(1, args.e2e_passes)):
+            dist.barrier()
+            t0 = time.perf_counter()
+            stats = pipeline.fastqs_to_images(files, tmp / ("img%d" % rep), k=args.k, mapping_code=args.mapping,
+                                              io_threads=threads, engine=eng)
+            dt = time.perf_counter() - t0
+            ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
+            mine = torch.tensor([dt if ok else -1.0], dtype=torch.float64, device=red_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_pass.append([float(x.item()) for x in every])
+        bases = world * nfiles * reads * args.readlen
+        worst = [max(p) for p in per_pass]
+        mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
+        res = {"files_per_rank": nfiles, "reads_per_file": reads, "io_threads_per_rank": threads,
+               "gbases_per_s": bases / worst[mid] / 1e9, "seconds": worst[mid], "passes_s_by_rank": per_pass,
+               "all_files_ok": all(min(p) > 0 for p in per_pass),
+               "note": "plain-text files -> PNGs on every rank at once, page cache warm; aggregate = all ranks' bases / "
+                       "slowest rank, median pass"}
+    except Exception as e:  # a side measurement: never lose the bench line over it
+        res = {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 def config4(args, device_index):
@@ -487,6 +546,11 @@ def main():
         elapsed = float(t.item())
 
     bad = int((status != 0).sum().item())
+    e2e_ranks = None
+    if world > 1 and not args.no_e2e:   # (every rank takes part: it is a node-level measurement)
+        del hist, img
+        torch.cuda.empty_cache()
+        e2e_ranks = end_to_end_ranks(eng, args, rank, world, dist, red_dev)
     count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     image_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
@@ -543,6 +607,8 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": count_ms},
         }
+        if e2e_ranks is not None:
+            out["end_to_end"] = e2e_ranks
         if world == 1 and not args.no_config4 and args.k <= 7:
             try:
                 out["config4"] = config4(args, local_rank)

@@ -198,7 +198,7 @@ def test_bench_script_runs_end_to_end(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
                           "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5", "--e2e-files", "6",
-                          "--e2e-reads", "5000"],
+                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -211,10 +211,19 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert "workload" in d["config"]
+    assert r["kernel"] == "vk_count_dense_kernel" and "vk_count_dense_kernel(+check)" in d["kernel_ms"]
     e = d["end_to_end"]
     for leg in ("plain_text", "fq_gz"):
         assert e[leg]["all_files_ok"] and e[leg]["pngs"] == 6 and e[leg]["gbases_per_s"] > 0
+        assert len(e[leg]["passes_s"]) == 3 and e[leg]["seconds"] == sorted(e[leg]["passes_s"])[1]     # the median
+        assert {"stage_wait_s", "upload_s", "inflate_s", "kernels_s", "png_tail_s"} <= set(e[leg]["where_the_median_pass_went_s"])
     assert e["fq_gz"]["file_bytes"] < e["plain_text"]["file_bytes"] and e["gz_pngs_identical_to_plain"]
+    c4 = d["config4"]                                   # BASELINE configs[3] as a side leg: k=9 cgr, both distributions
+    assert c4["k"] == 9 and c4["samples"] == 6
+    for leg in ("dist0", "dist1"):
+        assert c4[leg]["bad_status_samples"] == 0 and c4[leg]["count_ms"] > 0
+        rr = c4[leg]["roofline"]
+        assert rr["bound"] == "hbm" and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9 and rr["traffic"] is None
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():
@@ -228,13 +237,18 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--all-on-device0",
                           "--backend", "gloo", "--steps", "2", "--warmup", "1", "--total-samples", "24", "--pool", "6",
-                          "--reads", "20000"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+                          "--reads", "20000", "--e2e-files-per-rank", "3", "--e2e-reads", "5000"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["bad_status_samples"] == 0
     assert d["config"]["samples_per_gpu"] == 12
     assert d["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
-    assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d
+    assert "configs[2]" in d["config"]["workload"] and "cpu_baseline" not in d and "config4" not in d
+    assert len(d["ms_per_step_by_rank"]["all"]) == 2 and d["ms_per_step_by_rank"]["max"] <= d["ms_per_step"] * 1.0001
+    e = d["end_to_end"]                                  # every rank runs the file pipeline on its own files at once
+    assert e["all_files_ok"] and e["files_per_rank"] == 3 and e["gbases_per_s"] > 0
+    assert all(len(p) == 2 for p in e["passes_s_by_rank"]) and len(e["passes_s_by_rank"]) == 3
     # a launcher that disagrees with --gpus is an error, not a silent one-rank run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"))

@@ -179,3 +179,44 @@ def test_query_command_from_cleaned_reads(tmp_path):
     assert np.allclose(df[vocab].to_numpy(), want, rtol=1e-4, atol=1e-6)
     assert sorted(p.name for p in (tmp_path / "out" / "query_images").glob("*.png")) == \
         ["q1@00000450K+cgr+k7.png", "q2@00000300K+cgr+k7.png"]
+
+
+@pytest.mark.gpu
+def test_query_command_at_world_two_equals_single_rank(tmp_path):
+    """BASELINE config 5's shape on one GPU: `torchrun --nproc-per-node 2 -m varkoder_amd query ...` (both ranks on
+    cuda:0) shards the cleaned read files over the ranks -- images on the GPU, batched forward per rank -- and rank 0
+    writes the same predictions.csv a single rank writes (rows in input order, same seeds per sample)."""
+    import socket
+    import subprocess
+    import sys
+
+    import pandas as pd
+    from varkoder_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = tmp_path / "int" / "clean_reads"
+    clean.mkdir(parents=True)
+    for i in range(5):
+        (clean / f"q{i}.fq").write_bytes(synth.sample_fastq(40 + i, 2000 + 500 * i, 150, dist=i & 1).tobytes())
+    vocab = ["a", "b", "c", "d"]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    _tiny_model(tmp_path / "m.pt", len(vocab))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    common = ["query", "-l", str(tmp_path / "m.pt"), "--vocab", str(tmp_path / "vocab.txt"), "-k", "7", "-p", "cgr", "-P",
+              str(tmp_path / "int")]
+    one = subprocess.run([sys.executable, "-m", "varkoder_amd"] + common + [str(tmp_path / "out1")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "varkoder_amd"] + common +
+                         [str(tmp_path / "out2")], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(env, VARKODER_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = pd.read_csv(tmp_path / "out1" / "predictions.csv"), pd.read_csv(tmp_path / "out2" / "predictions.csv")
+    assert list(a.columns) == list(b.columns) and list(a["sample_id"]) == list(b["sample_id"]) == [f"q{i}" for i in range(5)]
+    assert list(a["query_basepairs"]) == list(b["query_basepairs"])
+    assert np.allclose(a[vocab].to_numpy(), b[vocab].to_numpy(), rtol=1e-5, atol=1e-7)
+    assert list(a["predicted_labels"].fillna("")) == list(b["predicted_labels"].fillna(""))

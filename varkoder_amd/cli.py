@@ -116,7 +116,10 @@ def run_convert(args):
 
 def run_query(args):
     """`varKoder query` from step C on (commands/query.py:188-324): images are made on the GPU and
-    stay there for the model's input transform; predictions.csv has the reference's columns."""
+    stay there for the model's input transform; predictions.csv has the reference's columns.
+    Under a launcher (one process per GPU) the inputs are sharded round-robin over the ranks -- every rank
+    makes its images and runs the model on its GPU -- and rank 0 writes predictions.csv in input order
+    (BASELINE config 5: images + batched inference on 8 GPUs; no data-path collective, one object gather)."""
     import numpy as np
     import torch
     from PIL import Image
@@ -124,75 +127,106 @@ def run_query(args):
     from .convert import get_metadata_from_img_filename
     from .engine import ImageEngine
     from .image import write_png
+    from .shard import shard_indices, world_info
     from .subsample import ladder_counts, split_name
+    rank, world, device = world_info()
     outdir = Path(args.outdir)
     if not args.overwrite and (outdir / "predictions.csv").exists():
         raise Exception("Output directory exists, use --overwrite if you want to overwrite it.")
-    model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
-    records, images = [], None
     if args.images:
-        paths = sorted(Path(args.input).rglob("*.png"))
-        if not paths:
-            raise Exception("No images found to query. Please check your input.")
+        inputs = sorted(Path(args.input).rglob("*.png"))
+    else:
+        src = Path(args.input)
+        if (src / "clean_reads").is_dir():
+            src = src / "clean_reads"
+        inputs = sorted(f for f in src.iterdir() if f.is_file() and f.name.endswith((".fq", ".fq.gz", ".fastq", ".fastq.gz")))
+    if not inputs:
+        raise Exception("No images found to query. Please check your input.")
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)        # control plane only
+    mine = shard_indices(len(inputs), rank, world)
+    model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
+    records, images, order = [], None, []   # order: index of each record's input in `inputs`
+    eng = None
+    if args.images:
         arrays = []
-        for p in paths:
+        for i in mine:
+            p = inputs[i]
             im = Image.open(p)
             md = get_metadata_from_img_filename(p)
             labels, qual, sd = Q.image_metadata(im.info)
             records.append(dict(path=str(p), sample=md["sample"], bp=md["bp"], k=md["img_kmer_size"],
                                 mapping=md["img_kmer_mapping"], labels=labels, qual=qual, freq_sd=sd))
             arrays.append(np.array(im))
+            order.append(i)
         shapes = {a.shape for a in arrays}
-        if len(shapes) != 1:
+        if len(shapes) > 1:
             raise Exception("Images of different sizes in one query are not supported.")
-        eng = ImageEngine(k=records[0]["k"], mapping="cgr")
-        images = torch.from_numpy(np.stack(arrays)).to(eng.device)
+        if arrays:
+            eng = ImageEngine(k=records[0]["k"], mapping="cgr", device=device)
+            images = torch.from_numpy(np.stack(arrays)).to(eng.device)
     else:
-        src = Path(args.input)
-        if (src / "clean_reads").is_dir():
-            src = src / "clean_reads"
-        files = sorted(f for f in src.iterdir() if f.is_file() and f.name.endswith((".fq", ".fq.gz", ".fastq", ".fastq.gz")))
-        if not files:
-            raise Exception("No images found to query. Please check your input.")
-        eng = ImageEngine(k=args.kmer_size, mapping=args.kmer_mapping)
         max_bp = None if str(args.max_bp) == "0" else parse_size(args.max_bp)
         rng = np.random.default_rng(args.seed)
-        dev, offs, lens = eng.upload_files(files)
+        # one seed per sample in input order, as image.py:1017 -- drawn for every input on every rank
+        seeds = [int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63) for i in range(len(inputs))]
         hists, keep = [], []
-        for i, f in enumerate(files):          # one seed per sample, as image.py:1017
-            sample = str(f.name.removesuffix("".join(f.suffixes)))
-            seed = int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63)
-            rec = ladder_counts(eng, dev, offs[i:i + 1], lens[i:i + 1], seed=seed, max_bp=max_bp, is_query=True)[0]
-            if rec["error"] or not rec["steps"]:
-                eprint("SPLIT FAIL:", f, "-", rec["error"])
-                continue
-            bp, hist, _ = rec["steps"][0]
-            name = split_name(sample, bp) + f"+{args.kmer_mapping}+k{args.kmer_size}.png"
-            path = str(outdir / "query_images" / name) if args.keep_images else name
-            records.append(dict(path=path, sample=sample, bp=int(bp / 1000) * 1000, k=args.kmer_size,
-                                mapping=args.kmer_mapping, labels="", qual=bool("False"), freq_sd=0.0))
-            hists.append(hist)
-            keep.append(name)
-        if not hists:
+        if mine:
+            eng = ImageEngine(k=args.kmer_size, mapping=args.kmer_mapping, device=device)
+            files = [inputs[i] for i in mine]
+            dev, offs, lens = eng.upload_files(files)
+            for j, (i, f) in enumerate(zip(mine, files)):
+                sample = str(f.name.removesuffix("".join(f.suffixes)))
+                rec = ladder_counts(eng, dev, offs[j:j + 1], lens[j:j + 1], seed=seeds[i], max_bp=max_bp, is_query=True)[0]
+                if rec["error"] or not rec["steps"]:
+                    eprint("SPLIT FAIL:", f, "-", rec["error"])
+                    continue
+                bp, hist, _ = rec["steps"][0]
+                name = split_name(sample, bp) + f"+{args.kmer_mapping}+k{args.kmer_size}.png"
+                path = str(outdir / "query_images" / name) if args.keep_images else name
+                records.append(dict(path=path, sample=sample, bp=int(bp / 1000) * 1000, k=args.kmer_size,
+                                    mapping=args.kmer_mapping, labels="", qual=bool("False"), freq_sd=0.0))
+                hists.append(hist)
+                keep.append(name)
+                order.append(i)
+            if hists:
+                images = eng.images(torch.stack(hists))
+                if args.keep_images:
+                    (outdir / "query_images").mkdir(parents=True, exist_ok=True)
+                    host = images.cpu().numpy()
+                    for j, name in enumerate(keep):
+                        write_png(host[j], outdir / "query_images" / name, [], 0, QUAL_THRESH, args.kmer_mapping)
+    if rank == 0:
+        if args.single_label:
+            eprint("This is a single label classification model, each input may will have only one prediction.")
+        else:
+            eprint("This is a multilabel classification model, each input may have 0 or more predictions.")
+    probs = None
+    if images is not None:
+        probs = Q.probabilities(eng, images, model, batch_size=args.max_batch_size, multilabel=not args.single_label,
+                                input_size=args.input_size, half=args.half)
+    parts = [(order, records, None if probs is None else np.asarray(probs))]
+    if world > 1:
+        import torch.distributed as dist
+        bucket = [None] * world if rank == 0 else None
+        dist.gather_object(parts[0], bucket, dst=0)
+        parts = bucket if rank == 0 else []
+    if rank == 0:
+        rows = sorted(((i, r, p) for o, rs, ps in parts if ps is not None for i, r, p in zip(o, rs, ps)), key=lambda t: t[0])
+        if not rows:
             raise Exception("No images found to query. Please check your input.")
-        images = eng.images(torch.stack(hists))
-        if args.keep_images:
-            (outdir / "query_images").mkdir(parents=True, exist_ok=True)
-            host = images.cpu().numpy()
-            for j, name in enumerate(keep):
-                write_png(host[j], outdir / "query_images" / name, [], 0, QUAL_THRESH, args.kmer_mapping)
-    if args.single_label:
-        eprint("This is a single label classification model, each input may will have only one prediction.")
-    else:
-        eprint("This is a multilabel classification model, each input may have 0 or more predictions.")
-    probs = Q.probabilities(eng, images, model, batch_size=args.max_batch_size, multilabel=not args.single_label,
-                            input_size=args.input_size, half=args.half)
-    df = Q.predictions_frame(records, probs, vocab, args.model, args.threshold, not args.single_label,
-                             args.include_probs)
-    outdir.mkdir(parents=True, exist_ok=True)
-    df.to_csv(outdir / "predictions.csv", index=False)
-    eprint("Predictions saved to", str(outdir / "predictions.csv"))
-    eng.close()
+        df = Q.predictions_frame([r for _, r, _ in rows], np.stack([p for _, _, p in rows]), vocab, args.model,
+                                 args.threshold, not args.single_label, args.include_probs)
+        outdir.mkdir(parents=True, exist_ok=True)
+        df.to_csv(outdir / "predictions.csv", index=False)
+        eprint("Predictions saved to", str(outdir / "predictions.csv"))
+    if eng is not None:
+        eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def read_labels(path):

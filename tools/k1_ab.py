@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """A/B timing of experimental builds of the count kernel: python tools/k1_ab.py lib1.so lib2.so ...
 Each library runs in its own child process (one ctypes load per process).  Prints the K1 launch
-time for 1000 samples x 1M x 150 bp (pool of 64 distinct samples), k=7, and checks the histogram of
-sample 0 against the default build's."""
+time for 1000 samples x 1M x 150 bp (--pool distinct samples, default 64; --k, --samples, --dist), first for the
+library in the tree with its default kernel and with VKIMG_K1_CLASSIC=1, then for every library named; the hash
+of the first 64 histograms shows whether the builds agree."""
 import subprocess
 import sys
 

@@ -32,7 +32,7 @@ def write(i):
 with ThreadPoolExecutor(16) as ex:
     list(ex.map(write, range(nfiles)))
 del host
-for bb in (3 << 30, 5 << 30, 9 << 30, 16 << 30):
+for bb in [int(x) << 30 for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("3", "5", "9", "16"))]:
     for rep in range(2):
         t0 = time.perf_counter()
         st = pipeline.fastqs_to_images(files, tmp / f"img{bb}_{rep}", k=7, mapping_code="varKode", io_threads=16, engine=eng,

@@ -821,6 +821,13 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
 // LDS: 64 KiB histogram + 16 x 1 KiB exchange = exactly half of a CU's 160 KiB, two workgroups per CU
 // (tools/occupancy_census.hip: they do co-reside); the range-start scratch lives in the wave's buffer.
 
+// Timing diagnostics (results are wrong with either): -DVK_DIAG_NO_DSADD drops the histogram atomics of the dense
+// kernel's heavy stage, -DVK_DIAG_NO_HEAVY the whole heavy stage (line pass, hand-over and loads remain).
+#ifdef VK_DIAG_NO_DSADD
+#define VK_DSADD(a) "s_nop 0\n\t"
+#else
+#define VK_DSADD(a) "ds_add_u32 " a ", %17\n\t"
+#endif
 template <int K>
 __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t ok, uint32_t lds_base,
                                              uint32_t& probe_addr, unsigned long long& probe_mask) {
@@ -854,14 +861,14 @@ __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t o
             "v_add_co_u32_e64 %0, %6, %0, %0\n\t"
             "v_add_co_u32_e64 %0, %7, %0, %0\n\t"
             "v_add_co_u32_e64 %0, %8, %0, %0\n\t"
-            "s_mov_b64 exec, %1\n\tds_add_u32 %9, %17\n\t"
-            "s_mov_b64 exec, %2\n\tds_add_u32 %10, %17\n\t"
-            "s_mov_b64 exec, %3\n\tds_add_u32 %11, %17\n\t"
-            "s_mov_b64 exec, %4\n\tds_add_u32 %12, %17\n\t"
-            "s_mov_b64 exec, %5\n\tds_add_u32 %13, %17\n\t"
-            "s_mov_b64 exec, %6\n\tds_add_u32 %14, %17\n\t"
-            "s_mov_b64 exec, %7\n\tds_add_u32 %15, %17\n\t"
-            "s_mov_b64 exec, %8\n\tds_add_u32 %16, %17\n\t"
+            "s_mov_b64 exec, %1\n\t" VK_DSADD("%9") 
+            "s_mov_b64 exec, %2\n\t" VK_DSADD("%10") 
+            "s_mov_b64 exec, %3\n\t" VK_DSADD("%11") 
+            "s_mov_b64 exec, %4\n\t" VK_DSADD("%12") 
+            "s_mov_b64 exec, %5\n\t" VK_DSADD("%13") 
+            "s_mov_b64 exec, %6\n\t" VK_DSADD("%14") 
+            "s_mov_b64 exec, %7\n\t" VK_DSADD("%15") 
+            "s_mov_b64 exec, %8\n\t" VK_DSADD("%16") 
             "s_mov_b64 exec, %18"
             : "+v"(w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
             : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(one), "s"(exec_in)
@@ -1003,6 +1010,10 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
         auto round_count = [&](uint32_t n, uint4 q, bool probe) __attribute__((always_inline)) {
+#ifdef VK_DIAG_NO_HEAVY
+            asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+            return;
+#endif
             uint32_t C, IV, SEQ;
             vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
             const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
@@ -1086,16 +1097,29 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 if ((wp[3] >> 6) == r) xb[wp[3] & 63u] = r3;
                 if ((wtag >> 6) == r) atomicOr(&xb[wtag & 63u].x, vkl::kGranuleStartTag);
             };
-            if (rounds != 0u) {
-                for (uint32_t r = 0; r + 1u < rounds; ++r) {
+            if (rounds >= 2u) {
+                // The last two rounds' granules are taken out of the buffer first, so that the piece's registers are
+                // free -- and the next piece's loads in flight -- under the arithmetic of BOTH rounds (-0.5 % on 512
+                // distinct samples; the 9 % such a launch loses against one on 64 samples, whose lines the
+                // workgroups of an XCD share in L2, is not the loads' latency).
+                for (uint32_t r = 0; r + 2u < rounds; ++r) {
                     put(r);
-                    const uint4 q = xb[lane_now()];
+                    const uint4 q = xb[lane];
                     round_count(64u, q, false);
                 }
+                put(rounds - 2u);
+                const uint4 qa = xb[lane];
                 put(rounds - 1u);
-                const uint4 q = xb[lane_now()];
+                const uint4 qb = xb[lane];
                 put(rounds);          // what is left stays in the buffer for the next piece
-                load_piece(it + 1);   // (it + 1 < npieces on this path) -- under the last round's arithmetic
+                load_piece(it + 1);   // (it + 1 < npieces on this path)
+                round_count(64u, qa, false);
+                round_count(64u, qb, true);
+            } else if (rounds == 1u) {
+                put(0u);
+                const uint4 q = xb[lane];
+                put(1u);
+                load_piece(it + 1);
                 round_count(64u, q, true);
             } else {
                 put(0u);

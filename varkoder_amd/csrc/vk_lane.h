@@ -164,7 +164,8 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
             // table lookup on the low 3 bits: expected high bits (case folded) | code
             const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
             const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
-            C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+            // (the first field of each string is a plain two-operand AND: half the issue cost of v_and_or)
+            C = j == 0 ? (x & 0x03030303u) : and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
             uint32_t nz, eq;
             if (ASCII) {
                 // every byte of t and x is below 0x80, so plain byte-wise adds cannot carry out:
@@ -176,8 +177,8 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
                 // bit 7 := low 7 bits equal 0x0A and bit 7 of t clear
                 eq = ~(xor_add_k(t & k7f, 0x0A0A0A0Au, k7f) | t);
             }
-            IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
-            NL = and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
+            IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+            NL = j == 0 ? ((eq >> 7) & 0x01010101u) : and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
         }
         o.C[g] = C;
         o.IV[g] = IV;
@@ -511,8 +512,11 @@ VKL_FN void newline_mask64(const uint32_t d[16], uint32_t& lo, uint32_t& hi) {
 #pragma unroll
 #endif
     for (int k = 0; k < 8; ++k) {
-        const uint32_t f0 = ((d[2 * k] ^ 0x75757575u) + 0x01010101u) & 0x80808080u;
-        const uint32_t f1 = ((d[2 * k + 1] ^ 0x75757575u) + 0x01010101u) & 0x80808080u;
+        // (xor and add as ONE v_xad_u32: measured on MI355X, a three-operand op costs ~1.8 ns of a SIMD's issue
+        // time at 8 waves per SIMD, two two-operand ops with literals ~2.1 -- and the caller's ASCII test has
+        // already waited for the loads, so the asm is never the first reader of a register in flight)
+        const uint32_t f0 = xor_add_k(d[2 * k], 0x75757575u, 0x01010101u) & 0x80808080u;
+        const uint32_t f1 = xor_add_k(d[2 * k + 1], 0x75757575u, 0x01010101u) & 0x80808080u;
         v[k] = udot4(f1, 0x80402010u, udot4(f0, 0x08040201u, 0u));  // (8 ordered flags) << 7
     }
     lo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
@@ -571,11 +575,11 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
         const uint32_t t = T[j];
         const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
         const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
-        C = and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+        C = j == 0 ? (x & 0x03030303u) : and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
         const uint32_t nz = x + 0x7C7C7C7Cu;
         const uint32_t eq = xor_add_k(t, 0x75757575u, 0x01010101u);
-        IV = and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
-        NL = and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
+        IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+        NL = j == 0 ? ((eq >> 7) & 0x01010101u) : and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
     }
     const uint32_t low = (NL - 1u) & ~NL;  // everything below the first newline (all ones without one)
     Cout = C;

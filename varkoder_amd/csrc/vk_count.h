@@ -217,7 +217,7 @@ __device__ __forceinline__ void windows_lds(uint32_t ch, const uint32_t C[4], co
     for (int g = 0; g < 4; ++g) {
         // even bits: OK of positions 0..15 of this dword; odd bits: the same rotated by 8
         // positions -> shifting out the top bit twice yields positions (i - 8, i), i = 15..8
-        uint32_t w = ok[g] | (vkl::alignbit(ok[g], ok[g], 16u) << 1);
+        uint32_t w = vkl::lshl_or(vkl::alignbit(ok[g], ok[g], 16u), 1u, ok[g]);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             uint32_t a[8];
@@ -834,7 +834,7 @@ __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t o
     static_assert(2 * K + 2 <= 16, "paired extraction needs the field << 2 to fit 16 bits");
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
     const uint32_t one = 1u;
-    uint32_t w = ok | (vkl::alignbit(ok, ok, 16u) << 1);
+    uint32_t w = vkl::lshl_or(vkl::alignbit(ok, ok, 16u), 1u, ok);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         uint32_t a[8];

@@ -109,6 +109,17 @@ VKL_FN uint32_t xor_and_k(uint32_t a, uint32_t b, uint32_t kmask) {  // a ^ (b &
 #endif
 }
 
+// (a << sh) | c as one instruction (v_lshlrev_b32 alone issues at the slow rate); sh must fold to a constant
+VKL_FN uint32_t lshl_or(uint32_t a, uint32_t sh, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(c));
+    return d;
+#else
+    return (a << sh) | c;
+#endif
+}
+
 struct LaneBits {
     uint32_t C[4];
     uint32_t IV[4];
@@ -165,7 +176,7 @@ VKL_FN uint32_t classify(const uint32_t d[16], LaneBits& o) {
             const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
             const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);  // 0..3 for a base, else some bit of 0xFC
             // (the first field of each string is a plain two-operand AND: half the issue cost of v_and_or)
-            C = j == 0 ? (x & 0x03030303u) : and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+            C = j == 0 ? (x & 0x03030303u) : lshl_or(x & 0x03030303u, 2 * j, C);
             uint32_t nz, eq;
             if (ASCII) {
                 // every byte of t and x is below 0x80, so plain byte-wise adds cannot carry out:
@@ -575,7 +586,7 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
         const uint32_t t = T[j];
         const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
         const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
-        C = j == 0 ? (x & 0x03030303u) : and_or_k(x << (2 * j), 0x03030303u << (2 * j), C);
+        C = j == 0 ? (x & 0x03030303u) : lshl_or(x & 0x03030303u, 2 * j, C);
         const uint32_t nz = x + 0x7C7C7C7Cu;
         const uint32_t eq = xor_add_k(t, 0x75757575u, 0x01010101u);
         IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);

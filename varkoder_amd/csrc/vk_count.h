@@ -1036,7 +1036,19 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         };
 
         load_piece(0);
+#ifdef VK_STAMPS
+        unsigned long long st_wait = 0, st_all = 0, st_t0 = 0, st_t1 = 0, st_prev = 0;
+        VK_STAMP(st_prev);
+#endif
         for (uint32_t it = 0; it < npieces; ++it) {
+#ifdef VK_STAMPS
+            VK_STAMP(st_t0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            VK_STAMP(st_t1);
+            st_wait += st_t1 - st_t0;
+            st_all += st_t0 - st_prev;
+            st_prev = st_t0;
+#endif
             if (it + 1 == npieces && (tail_bytes & 15u) != 0u) {
                 uint32_t tb = tail_bytes;
                 asm volatile("" : "+s"(tb));
@@ -1130,6 +1142,13 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         }
         ph_end = pph & 3u;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+#ifdef VK_STAMPS
+        if (lane == 0 && (blockIdx.x & 63u) == 0u) {  // [5] wait for the piece's bytes, [6] whole iterations, [7] pieces
+            atomicAdd(&g_vk_stamps[5], st_wait);
+            atomicAdd(&g_vk_stamps[6], st_all);
+            atomicAdd(&g_vk_stamps[7], static_cast<unsigned long long>(npieces));
+        }
+#endif
     }
     if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
 

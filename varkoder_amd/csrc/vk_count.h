@@ -277,7 +277,9 @@ __device__ __forceinline__ bool probe_is_hot(uint32_t addr, unsigned long long m
     if (__builtin_popcountll(mask) < 8) return false;
     const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(addr), __builtin_ctzll(mask)));
     const unsigned long long eq = __ballot(addr == first) & mask;
-    return __builtin_popcountll(eq) * 8 >= __builtin_popcountll(mask) * 7;
+    // an eighth of the counting lanes (and at least four) on ONE counter: never among unrelated k-mers, always in
+    // a wave that holds repeats beside ordinary reads (7 of 8 lanes, the first rule, missed those mixtures)
+    return __builtin_popcountll(eq) >= 4 && __builtin_popcountll(eq) * 8 >= __builtin_popcountll(mask);
 }
 
 __device__ __forceinline__ bool probe_few_groups(uint32_t addr, unsigned long long mask) {
@@ -329,79 +331,90 @@ __device__ __forceinline__ bool piece_is_homopolymer(uint32_t ch, const uint32_t
     return __all(homo);
 }
 
-// Tandem repeats.  The period P (1..8 bases) is read off one lane whose first 32 positions are all countable;
-// a lane group g (16 positions, every window countable) repeats with it when the bases its windows cover --
-// the last K - 1 of the word before and its own sixteen -- equal themselves P positions on.  Then the window
-// ending at position 16g + j (j < P) stands for every position of the group that is congruent to j:
-// add(field, n) is called for it, by ONE lane for all lanes that hold the same field there (all of them when the
-// reads sit alike in their blocks, P sets otherwise: 64 adds on one counter would be executed one after the
-// other), n = the positions it stands for.  Such groups leave ok[]; what remains (read ends, other reads) is for
-// the caller to count as usual.  Returns how many groups of this lane went this way.
+// Tandem repeats.  The period P (1 .. min(8, K) bases) is read off one lane whose first 32 positions are all
+// countable; a lane group g (16 positions, every window countable) repeats with it when the bases its windows cover
+// -- the last K - 1 of the word before and its own sixteen -- equal themselves P positions on.  Then the window
+// ending at position 16g + j (j < P) stands for every position of the group that is congruent to j, and the window
+// ending at 16g (K >= P bases of a P-periodic string) names the repeat unit and its phase: the lanes of the wave that
+// hold the same one there hold the same windows at every j.  They are found ONCE per group (up to eight classes;
+// what is left stands alone), and one lane per class calls add(field, n) for all of them, n = the positions the
+// window stands for x the lanes of the class -- 64 adds on one counter would be executed one after the other.
+// Such groups leave ok[]; what remains (read ends, other reads) is for the caller to count as usual.
+// Returns (wave-uniform) how many groups of the wave went this way.
 template <int K, typename Add>
 __device__ __forceinline__ uint32_t count_repeats(const uint32_t (&v)[5], uint32_t (&ok)[4], int lane, Add add) {
+    constexpr uint32_t kMaxP = K < 8 ? K : 8;
     uint32_t P = 0, handled = 0;
     {
-        const unsigned long long cand = __ballot(ok[0] == 0x55555555u && ok[1] == 0x55555555u);
-        if (cand != 0ull) {
+        // (up to four lanes are asked: in a wave that holds repeats beside ordinary reads the first one may be ordinary)
+        unsigned long long cand = __ballot(ok[0] == 0x55555555u && ok[1] == 0x55555555u);
+        for (int tries = 0; tries < 4 && cand != 0ull && P == 0u; ++tries) {
             const int src = __builtin_ctzll(cand);
+            cand &= cand - 1ull;
             const unsigned long long x = (static_cast<unsigned long long>(lane_bcast(v[2], src)) << 32) | lane_bcast(v[1], src);
 #pragma unroll
-            for (uint32_t p = 8; p >= 1; --p)
+            for (uint32_t p = kMaxP; p >= 1; --p)
                 if ((((x >> (2u * p)) ^ x) << (2u * p)) == 0ull) P = p;  // bits [0, 64 - 2p) of the difference
         }
     }
     if (P == 0u) return 0u;
     const uint32_t sh2 = 2u * P;
     const uint32_t himask = 0xFFFFFFFFu >> sh2;
+    constexpr uint32_t kField = (1u << (2 * K)) - 1u;
+    // positions of a group (16) congruent to j modulo P: q + (j < r), q = 16 / P, r = 16 % P -- from a table: a division
+    // by the run-time P, one per window, was 140 of the hot path's vector instructions
+    const uint32_t q16 = static_cast<uint32_t>((0x1084321510ull >> (5u * (P - 1u))) & 31ull);  // 16, 8, 5, 4, 3, 2, 2, 2
+    const uint32_t r16 = 16u - q16 * P;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint32_t lo = v[g], hi = v[g + 1];
         const uint32_t dlo = (vkl::alignbit(hi, lo, sh2) ^ lo) & (0xFFFFFFFFu << (32 - 2 * (K - 1)));
         const uint32_t dhi = ((hi >> sh2) ^ hi) & himask;
         const bool rep = ok[g] == 0x55555555u && (dlo | dhi) == 0u;
-        if (__any(rep)) {
-            if (rep) {
+        const unsigned long long repmask = __ballot(rep);
+        if (repmask == 0ull) continue;
+        handled += static_cast<uint32_t>(__builtin_popcountll(repmask));
+        // classes of lanes that hold the same unit at the same phase: leaders (one lane each) and sizes
+        const uint32_t key = vkl::alignbit(hi, lo, static_cast<uint32_t>(32 - 2 * (K - 1))) & kField;  // the window ending at 16g
+        uint32_t cnt = 1u;                        // lanes beyond the eighth class stand alone
+        unsigned long long leaders = 0ull, left = repmask;
+        for (uint32_t t = 0; t < 8 && left != 0ull; ++t) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), __builtin_ctzll(left)));
+            const unsigned long long eq = __ballot(key == first) & left;   // (every lane with this key is still in `left`)
+            if (key == first) cnt = static_cast<uint32_t>(__builtin_popcountll(eq));
+            leaders |= eq & (~eq + 1ull);
+            left &= ~eq;
+        }
+        leaders |= left;
+        if ((leaders >> lane) & 1ull) {
 #pragma unroll
-                for (uint32_t j = 0; j < 8; ++j) {
-                    if (j < P) {  // (P is wave-uniform)
-                        const int sh = 32 + 2 * (static_cast<int>(j) - K + 1);   // bit offset of the window in [lo | hi]
-                        const uint32_t f = (sh < 32 ? vkl::alignbit(hi, lo, static_cast<uint32_t>(sh)) : (hi >> (sh - 32))) &
-                                           ((1u << (2 * K)) - 1u);
-                        const uint32_t n = (16u - j + P - 1u) / P;               // positions of the group congruent to j
-                        unsigned long long left = __ballot(true);
-                        bool done = false;
-                        for (uint32_t t = 0; t < 8 && left; ++t) {
-                            const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(f), __builtin_ctzll(left)));
-                            const bool same = !done && f == first;
-                            const unsigned long long eq = __ballot(same);
-                            if (same) {
-                                if (lane == __builtin_ctzll(eq)) add(f, n * static_cast<uint32_t>(__builtin_popcountll(eq)));
-                                done = true;
-                            }
-                            left &= ~eq;
-                        }
-                        if (!done) add(f, n);
-                    }
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (j < P) {  // (P is wave-uniform)
+                    const int sh = 32 + 2 * (static_cast<int>(j) - K + 1);   // bit offset of the window in [lo | hi]
+                    const uint32_t f = (sh < 32 ? vkl::alignbit(hi, lo, static_cast<uint32_t>(sh)) : (hi >> (sh - 32))) & kField;
+                    add(f, __umul24(q16 + (j < r16 ? 1u : 0u), cnt));          // positions of the group congruent to j x lanes
                 }
-                ok[g] = 0u;
-                ++handled;
             }
         }
+        if (rep) ok[g] = 0u;
     }
     return handled;
 }
 
-// did at least a third of the wave's groups that had windows go the short way?
+// did at least a third of the wave's groups that had windows go the short way?  (handled: count_repeats' result)
 __device__ __forceinline__ bool repeats_dominate(uint32_t handled, const uint32_t ok_in[4]) {
-    const uint32_t had = (ok_in[0] != 0u) + (ok_in[1] != 0u) + (ok_in[2] != 0u) + (ok_in[3] != 0u);
-    const uint32_t sum_h = lane_bcast(wave_inclusive_sum(handled), 63), sum_g = lane_bcast(wave_inclusive_sum(had), 63);
-    return sum_h * 3u >= sum_g && sum_h != 0u;
+    if (handled == 0u) return false;
+    const uint32_t had = static_cast<uint32_t>(__builtin_popcountll(__ballot(ok_in[0] != 0u)) + __builtin_popcountll(__ballot(ok_in[1] != 0u)) +
+                                               __builtin_popcountll(__ballot(ok_in[2] != 0u)) + __builtin_popcountll(__ballot(ok_in[3] != 0u)));
+    return handled * 3u >= had;
 }
 
-// Returns whether the piece was low-complexity indeed (the caller stays in this mode while it is).
+// Returns what the piece was: 0 not low-complexity after all, 1 homopolymer, 2 tandem repeats (the caller stays in
+// this mode while it is not 0).  try_homopolymer: false skips the homopolymer test (the caller passes it while the
+// pieces are tandem repeats, with a look every eighth piece: poly-A is then still exact, as period 1).
 template <int K>
-__device__ bool windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok_in[4], uint32_t* hist, uint32_t lds_base,
-                                int lane, uint32_t& probe_addr, unsigned long long& probe_mask) {
+__device__ uint32_t windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok_in[4], uint32_t* hist, uint32_t lds_base,
+                                    int lane, bool try_homopolymer, uint32_t& probe_addr, unsigned long long& probe_mask) {
     const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
     // the probe for the next piece: the window that ends at position 40 of every lane, however it gets counted
@@ -413,11 +426,11 @@ __device__ bool windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t
     }
     // Homopolymer pieces (poly-A / poly-G tails, the common low-complexity case): every window of a lane is
     // the same k-mer and the lane adds its window count once -- one ds_add per lane and piece instead of 64.
-    {
+    if (try_homopolymer) {
         uint32_t n, base;
         if (piece_is_homopolymer<K>(ch, C, ok_in, n, base)) {
             if (n != 0u) atomicAdd(&hist[base * (((1u << (2 * K)) - 1u) / 3u)], n);
-            return true;
+            return 1u;
         }
     }
     uint32_t ok[4] = {ok_in[0], ok_in[1], ok_in[2], ok_in[3]};
@@ -425,10 +438,12 @@ __device__ bool windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t
         __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(lds_base + 4u * f)),
                                n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     });
-    uint32_t pa;
-    unsigned long long pm;
-    windows_lds<K>(ch, C, ok, lds_base, pa, pm);
-    return repeats_dominate(handled, ok_in);
+    if (__any((ok[0] | ok[1] | ok[2] | ok[3]) != 0u)) {
+        uint32_t pa;
+        unsigned long long pm;
+        windows_lds<K>(ch, C, ok, lds_base, pa, pm);
+    }
+    return repeats_dominate(handled, ok_in) ? 2u : 0u;
 }
 
 // ---- read subsampling (vk_count_sampled_device; vk_lane.h: sample_hash) ------------------------
@@ -765,14 +780,14 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
-        bool hot = false;  // the last piece looked low-complexity: see windows_lds_hot
+        uint32_t hot = 0, hot_tick = 0;  // the last piece looked low-complexity (1 homopolymer, 2 tandem): see windows_lds_hot
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok) __attribute__((always_inline)) {
             uint32_t pa;
             unsigned long long pm;
-            bool still = false;
-            if (!hot) windows_lds<K>(ch, C, ok, hist_base, pa, pm);
-            else still = windows_lds_hot<K>(ch, C, ok, hist, hist_base, lane, pa, pm);
-            hot = still || probe_is_hot(pa, pm);
+            uint32_t still = 0;
+            if (hot == 0u) windows_lds<K>(ch, C, ok, hist_base, pa, pm);
+            else still = windows_lds_hot<K>(ch, C, ok, hist, hist_base, lane, hot != 2u || ((++hot_tick) & 7u) == 0u, pa, pm);
+            hot = still != 0u ? still : (probe_is_hot(pa, pm) ? 1u : 0u);
         };
         SubWave sw = {0, 0, 0, 0};
         if constexpr (SUB) {
@@ -927,12 +942,15 @@ __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 
     if (first && lane == 0 && has_pre) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
     uint32_t pa;
     unsigned long long pm;
-    bool still = false;
+    uint32_t still = 0;
+    uint32_t tick = st.tick & 0x7FFFFFFFu;   // bit 31 of the caller's tick: the last low-complexity piece was tandem repeats
     if (st.hot == 0u) windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
-    else still = windows_lds_hot<K>(ch, lb.C, ok, hist, hist_base, lane, pa, pm);
-    uint32_t tick = st.tick;
-    st.hot = (still || probe_low_complexity(pa, pm, tick)) ? 1u : 0u;
-    st.tick = tick;
+    else {
+        ++tick;
+        still = windows_lds_hot<K>(ch, lb.C, ok, hist, hist_base, lane, (st.tick >> 31) == 0u || (tick & 7u) == 0u, pa, pm);
+    }
+    st.hot = (still != 0u || probe_low_complexity(pa, pm, tick)) ? 1u : 0u;
+    st.tick = (tick & 0x7FFFFFFFu) | (still == 2u ? 0x80000000u : 0u);
     st.pph = pph + total;
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
     return st;

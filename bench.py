@@ -191,8 +191,9 @@ def end_to_end(eng, args):
     room = min(free, avail // 2)
     while nfiles > 16 and nfiles * reads * rec * 1.35 > room:
         nfiles //= 2
+    from varkoder_amd.engine import plain_route
     out = {"files": nfiles, "files_asked": args.e2e_files, "reads_per_file": reads, "read_len": args.readlen,
-           "io_threads": threads}
+           "io_threads": threads, "plain_text_route": plain_route(threads)}
     try:
         # generated on the device in slabs of 32 files and copied back (a 46 GB tensor at once would also do,
         # but the pool of the main measurement is still resident)
@@ -318,8 +319,9 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
         bases = world * nfiles * reads * args.readlen
         worst = [max(p) for p in per_pass]
         mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
+        from varkoder_amd.engine import plain_route
         res = {"files_per_rank": nfiles, "reads_per_file": reads, "io_threads_per_rank": threads,
-               "gbases_per_s": bases / worst[mid] / 1e9, "seconds": worst[mid], "passes_s_by_rank": per_pass,
+               "plain_text_route": plain_route(threads), "gbases_per_s": bases / worst[mid] / 1e9, "seconds": worst[mid], "passes_s_by_rank": per_pass,
                "all_files_ok": all(min(p) > 0 for p in per_pass),
                "note": "plain-text files -> PNGs on every rank at once, page cache warm; aggregate = all ranks' bases / "
                        "slowest rank, median pass"}

@@ -169,6 +169,23 @@ int vk_preprocess_device(vk_ctx* ctx, const uint8_t* d_img, uint32_t nimg, uint3
                          uint32_t out, const int32_t* bounds, const int32_t* coef, uint32_t kmax,
                          float mean, float stdv, float* d_out);
 
+/* Replaces: dsk opening and reading `-file <sample>.fq` (commands/image.py:771-796), for plain-text files: nfiles
+ * host regions -- each a page-aligned, read-only MAP_SHARED mapping of a whole file -- are copied to
+ * d_dst + dst_offsets[i] by DMA from the page-cache pages where they lie: no read() into a staging buffer (a copy
+ * that costs a core per ~3 GB/s; ranks that share a host's cores cannot feed a 57 GB/s link with it).
+ * registered (may be NULL): registered[i] != 0 says the caller has pinned region i with vk_host_register -- ahead of
+ * time, on another thread -- and will release it; any other region is registered for the duration of its copy
+ * (file i + 1 while file i is in flight) and released before the call returns.  The call synchronises.
+ * status[i] (host): 0 copied, 1 the pages could not be registered (the caller copies that file through its own
+ * buffer), 2 the copy failed.  Regions of 0 bytes are skipped. */
+int vk_upload_mapped(vk_ctx* ctx, void* d_dst, const uint64_t* dst_offsets, const void* const* h_src,
+                     const uint64_t* nbytes, const uint8_t* registered, uint32_t nfiles, uint32_t* status);
+
+/* Pin / release a host region for vk_upload_mapped (hipHostRegister / hipHostUnregister: the pages stay where they
+ * are, in the page cache).  Thread-safe; VK_EHIP if the platform refuses (the caller then leaves the flag 0). */
+int vk_host_register(vk_ctx* ctx, const void* p, uint64_t nbytes);
+int vk_host_unregister(vk_ctx* ctx, const void* p);
+
 /* Introspection used by bench.py / tests: workgroups and LDS bytes of the last
  * vk_count_device launch. */
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes);

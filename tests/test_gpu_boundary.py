@@ -129,6 +129,44 @@ def test_batched_pipeline_writes_reference_named_pngs(tmp_path):
     assert again == {}
 
 
+def test_plain_files_from_the_page_cache_equal_the_staged_route(tmp_path, monkeypatch):
+    """Plain-text files reach the GPU by DMA from their page-cache pages (engine.stage_files maps them,
+    vk_upload_mapped registers and copies them); VARKODER_AMD_MMAP=0 (and any rank with 16 I/O threads or more) reads them into the pinned staging buffer.
+    Same text in HBM either way -- sizes that are no multiple of 16 and of the page size, an empty file, a gzip
+    file in the same batch -- and the same PNGs from the pipeline."""
+    from varkoder_amd import engine as engine_mod, pipeline
+    from varkoder_amd.engine import ImageEngine
+    files, datas = [], []
+    for s, reads in enumerate((700, 1, 2048, 333)):
+        f = tmp_path / f"m{s}@{reads * 150 // 1000:08d}K.fq"
+        datas.append(_write_fastq(f, 60 + s, reads))
+        files.append(f)
+    empty = tmp_path / "e@00000000K.fq"
+    empty.write_bytes(b"")
+    gz = tmp_path / "z@00000105K.fq.gz"
+    datas_gz = _write_fastq(gz, 70, 700, gz=True)
+    batch = files[:2] + [empty, gz] + files[2:]
+    want = datas[:2] + [b"", datas_gz] + datas[2:]
+    eng = ImageEngine(k=7, mapping="cgr")
+    got = {}
+    for mapped in (True, False):
+        monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", mapped)
+        st = eng.stage_files(batch)
+        assert sorted(st["mapped"]) == ([0, 1, 4, 5] if mapped else [])
+        dev, offs, lens = eng.upload_staged(st)
+        host = dev.cpu().numpy()
+        for i, w in enumerate(want):
+            o, n = int(offs[i]), int(lens[i])
+            assert n == len(w) and bytes(host[o:o + n]) == w, (mapped, i)
+            assert not host[o + n:(o + n + 15) // 16 * 16].any()       # zero up to the 16-byte rounded end
+        out = tmp_path / ("img%d" % mapped)
+        stats = pipeline.fastqs_to_images(batch, out, k=7, mapping_code="cgr", engine=eng, batch_bytes=300000)
+        assert stats["e@00000000K"] == {"failed_step": "image"}
+        got[mapped] = {p.name: hashlib.sha256(p.read_bytes()).hexdigest() for p in sorted(out.glob("*.png"))}
+    eng.close()
+    assert len(got[True]) == 5 and got[True] == got[False]
+
+
 def test_cli_image_on_an_intermediate_folder(tmp_path):
     """`python -m varkoder_amd image INT -k 7 -p cgr -o OUT -f stats.csv -t`: same flags as the
     reference CLI (cli.py:69-166), entering at step D on a folder of split FASTQs."""

@@ -221,7 +221,20 @@ def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     real_empty = torch.empty
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "pin_memory"}))
-    st = eng.stage_files([tmp_path / "b.fq.gz", tmp_path / "a.fq", tmp_path / "c.fq.gz", tmp_path / "gone.fq"])
+    from varkoder_amd import engine as engine_mod
+    paths = [tmp_path / "b.fq.gz", tmp_path / "a.fq", tmp_path / "c.fq.gz", tmp_path / "gone.fq"]
+    # plain files are mapped, not read (the GPU copies them out of the page cache: vk_upload_mapped) ...
+    monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", True)
+    st = eng.stage_files(paths)
+    assert sorted(st["mapped"]) == [1] and bytes(st["mapped"][1][0]) == good and st["offs"][1] == 0
+    assert st["mapped"][1][2] is False                 # (no context here: nothing was pinned ahead)
+    assert st["disk"].tolist() == [len(zbytes), len(good), 0, 0] and st["lens"].tolist() == [0, len(good), 0, 0]
+    st["mapped"][1][1] = None
+    st["mapped"][1][0].close()
+    # ... or (VARKODER_AMD_MMAP=0; the default for a rank with 16 I/O threads or more) read into the staging buffer like the compressed ones
+    monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", False)
+    st = eng.stage_files(paths)
+    assert not st["mapped"]
     assert st["is_gz"].tolist() == [True, False, True, False]
     assert st["disk"].tolist() == [len(zbytes), len(good), 0, 0]
     assert st["lens"].tolist() == [0, len(good), 0, 0]              # a gzip file's text length comes from the GPU

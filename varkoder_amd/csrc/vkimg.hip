@@ -361,6 +361,65 @@ int vk_ctx_sync(vk_ctx* ctx) {
     return VK_OK;
 }
 
+int vk_host_register(vk_ctx* ctx, const void* p, uint64_t nbytes) {
+    if (!ctx || !p || nbytes == 0) return VK_EINVAL;
+    const hipError_t e = hipHostRegister(const_cast<void*>(p), nbytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return VK_EHIP;   // (ctx->last is left alone: this may run beside the context's own thread)
+    }
+    return VK_OK;
+}
+
+int vk_host_unregister(vk_ctx* ctx, const void* p) {
+    if (!ctx || !p) return VK_EINVAL;
+    return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? VK_OK : VK_EHIP;
+}
+
+int vk_upload_mapped(vk_ctx* ctx, void* d_dst, const uint64_t* dst_offsets, const void* const* h_src,
+                     const uint64_t* nbytes, const uint8_t* registered, uint32_t nfiles, uint32_t* status) {
+    if (!ctx || !d_dst || (nfiles && (!dst_offsets || !h_src || !nbytes || !status))) return VK_EINVAL;
+    std::vector<char> reg(nfiles, 0), mine(nfiles, 0);
+    auto pin = [&](uint32_t i) {   // the file's page-cache pages, pinned and mapped for the DMA engines
+        status[i] = 0u;
+        if (nbytes[i] == 0) return;
+        if (registered && registered[i]) {
+            reg[i] = 1;
+            return;
+        }
+        mine[i] = 1;
+        if (!h_src[i] || hipHostRegister(const_cast<void*>(h_src[i]), nbytes[i], hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            status[i] = 1u;
+            mine[i] = 0;
+        } else {
+            reg[i] = 1;
+        }
+    };
+    if (nfiles) pin(0);
+    int rc = VK_OK;
+    for (uint32_t i = 0; i < nfiles; ++i) {
+        if (reg[i]) {
+            const hipError_t e = hipMemcpyAsync(static_cast<uint8_t*>(d_dst) + dst_offsets[i], h_src[i], nbytes[i],
+                                                hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) {
+                ctx->last = e;
+                status[i] = 2u;
+                rc = VK_EHIP;
+            }
+        }
+        if (i + 1 < nfiles) pin(i + 1);   // while file i is in flight
+    }
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    for (uint32_t i = 0; i < nfiles; ++i)
+        if (mine[i]) (void)hipHostUnregister(const_cast<void*>(h_src[i]));
+    if (es != hipSuccess) {
+        ctx->last = es;
+        return VK_EHIP;
+    }
+    return rc;
+}
+
 int vk_set_mapping(vk_ctx* ctx, int k, const uint32_t* pix, uint32_t npix) {
     if (!ctx || k < 5 || k > 9) return VK_EINVAL;
     const uint32_t ncode = 1u << (2 * k);

@@ -4,6 +4,8 @@ PyTorch is used for device memory and the stream only; every computation is a ca
 through the C ABI of include/vkimg.h.  There is no CPU fallback.
 """
 import ctypes as C
+import mmap
+import os
 import sys
 
 import numpy as np
@@ -59,6 +61,18 @@ def bgzf_text_size(buf):
 # that really expands further overflows its slot and is inflated again into one of the size the first pass
 # reported (vk_inflate_device, VK_GZ_OVERFLOW).
 GZ_MAX_FIRST_RATIO = 64
+# How plain-text files reach the GPU: mapped and copied by DMA straight out of the page cache (stage_files /
+# vk_upload_mapped: next to no host work) or read() into the pinned staging buffer by the I/O threads (a core per
+# ~3 GB/s).  With 16 threads the second is 3-7 % faster on one GPU (both run at the link's rate; measured, DESIGN.md
+# 5); a rank that has fewer -- several ranks sharing a host's cores -- cannot feed its link that way.
+# VARKODER_AMD_MMAP=1 / 0 forces one or the other; unset: mapped when the rank has fewer than MAPPED_BELOW_THREADS.
+USE_MAPPED_UPLOAD = {"1": True, "0": False}.get(os.environ.get("VARKODER_AMD_MMAP", ""))
+MAPPED_BELOW_THREADS = 16
+
+
+def plain_route(threads):
+    """"mapped" or "staged": how stage_files brings plain-text files in for a rank with this many I/O threads."""
+    return "mapped" if (USE_MAPPED_UPLOAD if USE_MAPPED_UPLOAD is not None else threads < MAPPED_BELOW_THREADS) else "staged"
 
 
 class ImageEngine:
@@ -101,6 +115,9 @@ class ImageEngine:
         self.ncode = 4 ** k
 
     def close(self):
+        ex = self.__dict__.pop("_releaser", None)
+        if ex is not None:
+            ex.shutdown(wait=True)   # mapped files still being unpinned
         if getattr(self, "ctx", None):
             self.L.vk_ctx_destroy(self.ctx)
             self.ctx = None
@@ -201,6 +218,35 @@ class ImageEngine:
         for i in np.flatnonzero(is_gz):
             src[i] = pos
             pos += (int(disk[i]) + 15) // 16 * 16
+        # Plain files are not read at all where the platform allows it: they are mapped (MAP_SHARED, populated here,
+        # on the staging threads) and upload_staged has the GPU copy them straight out of the page cache
+        # (vk_upload_mapped) -- the read() into the pinned buffer, at ~3 GB/s per core, was what bounded plain-text
+        # input, not the 57 GB/s link.  A file that cannot be mapped goes through the buffer as before.
+        mapped = {}
+        threads = getattr(pool, "_max_workers", 1) if pool is not None else 1
+        if plain_route(threads) == "mapped":
+            def map_file(i):
+                if is_gz[i] or int(disk[i]) == 0:
+                    return None
+                try:
+                    fd = os.open(paths[i], os.O_RDONLY)
+                    try:
+                        if os.fstat(fd).st_size != int(disk[i]):
+                            return None
+                        mm = mmap.mmap(fd, int(disk[i]), flags=mmap.MAP_SHARED | getattr(mmap, "MAP_POPULATE", 0),
+                                       prot=mmap.PROT_READ)
+                    finally:
+                        os.close(fd)
+                except (OSError, ValueError):
+                    return None
+                view = np.frombuffer(mm, dtype=np.uint8)
+                # pinned for the DMA engines here, ahead of the copy and beside it (upload_staged pins what is not)
+                ctx = getattr(self, "ctx", None)
+                pinned_now = bool(ctx) and self.L.vk_host_register(ctx, C.c_void_p(view.ctypes.data), view.size) == _capi.VK_OK
+                return [mm, view, pinned_now]
+            for i, m in enumerate(mapper(map_file, range(n))):
+                if m is not None:
+                    mapped[i] = m
         stage_total = pos + 16
         slots = self.__dict__.setdefault("_pinned_slots", {})
         pinned = slots.get(slot)
@@ -213,6 +259,8 @@ class ImageEngine:
         def fill(i):
             o, nb = int(src[i]), int(disk[i])
             got = 0
+            if i in mapped:
+                return
             if nb:
                 try:
                     with open(paths[i], "rb") as f:
@@ -241,7 +289,30 @@ class ImageEngine:
         text_total = pos + 16
         return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
-                "paths": [str(p) for p in paths], "bgzf": bgzf}
+                "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped}
+
+    def _release_mapped(self, mapped):
+        """Unpin and unmap the files of a batch -- on a helper thread: it is a few milliseconds per batch that nothing
+        has to wait for (close() waits for it)."""
+        items = list(mapped.values())
+        mapped.clear()
+        ctx, L = self.ctx, self.L
+
+        def work():
+            for m in items:
+                mm, view, pinned_now = m
+                if pinned_now:
+                    L.vk_host_unregister(ctx, C.c_void_p(view.ctypes.data))
+                m[1] = view = None
+                try:
+                    mm.close()
+                except BufferError:
+                    pass
+        ex = self.__dict__.get("_releaser")
+        if ex is None:
+            from concurrent.futures import ThreadPoolExecutor
+            ex = self.__dict__["_releaser"] = ThreadPoolExecutor(1)
+        ex.submit(work)
 
     def upload_staged(self, staged, timings=None):
         """Device half: one H2D DMA of the plain text, one of the compressed files, and the gzip files
@@ -251,9 +322,33 @@ class ImageEngine:
         torch = _torch()
         pinned, plain_total, stage_total = staged["pinned"], staged["plain_total"], staged["stage_total"]
         offs, lens, is_gz = staged["offs"], staged["lens"].copy(), staged["is_gz"]
-        dev = torch.empty(staged["text_total"], dtype=torch.uint8, device=self.device)
-        if plain_total:
-            dev[:plain_total].copy_(pinned[:plain_total], non_blocking=True)
+        mapped = staged.get("mapped") or {}
+        if mapped:
+            # (zeroed: a mapped file brings no padding up to its 16-byte rounded end along)
+            dev = torch.zeros(staged["text_total"], dtype=torch.uint8, device=self.device)
+            idx = sorted(mapped)
+            views = [mapped[i][1] for i in idx]
+            srcp = (C.c_void_p * len(idx))(*[v.ctypes.data for v in views])
+            flags = np.array([1 if mapped[i][2] else 0 for i in idx], dtype=np.uint8)
+            st = np.zeros(len(idx), dtype=np.uint32)
+            _capi.check(self.ctx, self.L.vk_upload_mapped(
+                self.ctx, self._ptr(dev), np.ascontiguousarray(offs[idx]).ctypes.data_as(C.POINTER(C.c_uint64)), srcp,
+                np.ascontiguousarray(staged["disk"][idx]).ctypes.data_as(C.POINTER(C.c_uint64)),
+                flags.ctypes.data_as(C.POINTER(C.c_uint8)), len(idx), st.ctypes.data_as(C.POINTER(C.c_uint32))),
+                "vk_upload_mapped")
+            for j, i in enumerate(idx):
+                if st[j]:   # the pages could not be registered: through a pageable copy, once
+                    dev[int(offs[i]):int(offs[i]) + views[j].size].copy_(torch.from_numpy(views[j].copy()))
+            del views, srcp
+            self._release_mapped(mapped)
+            for i in np.flatnonzero(~is_gz):           # the files that could not be mapped lie in the staging buffer
+                if int(i) not in idx and int(staged["disk"][i]):
+                    o, nb = int(offs[i]), int(staged["disk"][i])
+                    dev[o:o + nb].copy_(pinned[o:o + nb], non_blocking=True)
+        else:
+            dev = torch.empty(staged["text_total"], dtype=torch.uint8, device=self.device)
+            if plain_total:
+                dev[:plain_total].copy_(pinned[:plain_total], non_blocking=True)
         gi = np.flatnonzero(is_gz & (staged["disk"] > 0))
         if gi.size:
             # the compressed bytes are not copied: the inflate kernels read them where they are, in the pinned

@@ -524,12 +524,13 @@ VKL_FN void newline_mask64(const uint32_t d[16], uint32_t& lo, uint32_t& hi) {
 #endif
     for (int k = 0; k < 8; ++k) {
         // (xor and add as ONE v_xad_u32: measured on MI355X, a three-operand op costs ~1.8 ns of a SIMD's issue
-        // time at 8 waves per SIMD, two two-operand ops with literals ~2.1 -- and the caller's ASCII test has
-        // already waited for the loads, so the asm is never the first reader of a register in flight)
+        // time at 8 waves per SIMD, two two-operand ops with literals ~2.1)
         const uint32_t f0 = xor_add_k(d[2 * k], 0x75757575u, 0x01010101u) & 0x80808080u;
         const uint32_t f1 = xor_add_k(d[2 * k + 1], 0x75757575u, 0x01010101u) & 0x80808080u;
         v[k] = udot4(f1, 0x80402010u, udot4(f0, 0x08040201u, 0u));  // (8 ordered flags) << 7
     }
+    // (plain C on purpose: hipcc puts the wait states a v_dot4 result needs in front of its OWN instructions, not
+    // in front of an asm statement that reads it -- the shifts fused by hand into v_lshl_or_b32 read stale masks)
     lo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
     hi = (v[4] >> 7) | (v[5] << 1) | (v[6] << 9) | (v[7] << 17);
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The file pipeline on plain-text files with few I/O threads (a rank that shares its host's cores with others):
-the staged route against the mapped one.  python tools/e2e_threads_probe.py [nfiles] [threads,threads,...]"""
+the staged route against the mapped one.  python tools/e2e_threads_probe.py [nfiles] [threads,threads,...] [gz]"""
 import shutil
 import sys
 import tempfile
@@ -23,6 +23,18 @@ for i in range(nfiles):
     p = tmp / f"s{i:04d}@{reads * 150 // 1000:08d}K.fq"
     p.write_bytes(host[int(offs[i % 8]):int(offs[i % 8]) + int(lens[i % 8])].tobytes())
     files.append(p)
+if len(sys.argv) > 3 and sys.argv[3] == "gz":      # the same files as .fq.gz (zlib level 1)
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def pack(p):
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)
+        q = Path(str(p) + ".gz")
+        q.write_bytes(co.compress(p.read_bytes()) + co.flush())
+        p.unlink()
+        return q
+    with ThreadPoolExecutor(16) as ex:
+        files = list(ex.map(pack, files))
 del host, fq
 for t in threads:
     for route in (False, True, False, True):

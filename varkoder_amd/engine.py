@@ -226,8 +226,10 @@ class ImageEngine:
         threads = getattr(pool, "_max_workers", 1) if pool is not None else 1
         if plain_route(threads) == "mapped":
             def map_file(i):
-                if is_gz[i] or int(disk[i]) == 0:
+                if int(disk[i]) == 0:
                     return None
+                if is_gz[i] and (int(disk[i]) < 28 or int(disk[i]) % 4096 == 0 or int(disk[i]) % 4096 > 4032):
+                    return None   # (the inflate kernels read a compressed file in place: its last page keeps room behind the end)
                 try:
                     fd = os.open(paths[i], os.O_RDONLY)
                     try:
@@ -243,6 +245,10 @@ class ImageEngine:
                 # pinned for the DMA engines here, ahead of the copy and beside it (upload_staged pins what is not)
                 ctx = getattr(self, "ctx", None)
                 pinned_now = bool(ctx) and self.L.vk_host_register(ctx, C.c_void_p(view.ctypes.data), view.size) == _capi.VK_OK
+                if is_gz[i] and not pinned_now:   # kernels cannot read what is not pinned: through the staging buffer
+                    view = None
+                    mm.close()
+                    return None
                 return [mm, view, pinned_now]
             for i, m in enumerate(mapper(map_file, range(n))):
                 if m is not None:
@@ -260,6 +266,12 @@ class ImageEngine:
             o, nb = int(src[i]), int(disk[i])
             got = 0
             if i in mapped:
+                view = mapped[i][1]
+                if is_gz[i] and view[3] & 4:
+                    m = bgzf_members(view)
+                    if m is not None:
+                        caps[i] = int(m[2].sum())
+                        bgzf[i] = m
                 return
             if nb:
                 try:
@@ -291,11 +303,11 @@ class ImageEngine:
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
                 "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped}
 
-    def _release_mapped(self, mapped):
-        """Unpin and unmap the files of a batch -- on a helper thread: it is a few milliseconds per batch that nothing
-        has to wait for (close() waits for it)."""
-        items = list(mapped.values())
-        mapped.clear()
+    def _release_mapped(self, mapped, which=None):
+        """Unpin and unmap files of a batch (all, or those named) -- on a helper thread: it is a few milliseconds per
+        batch that nothing has to wait for (close() waits for it)."""
+        keys = list(mapped) if which is None else list(which)
+        items = [mapped.pop(i) for i in keys]
         ctx, L = self.ctx, self.L
 
         def work():
@@ -323,10 +335,10 @@ class ImageEngine:
         pinned, plain_total, stage_total = staged["pinned"], staged["plain_total"], staged["stage_total"]
         offs, lens, is_gz = staged["offs"], staged["lens"].copy(), staged["is_gz"]
         mapped = staged.get("mapped") or {}
-        if mapped:
+        idx = [i for i in sorted(mapped) if not is_gz[i]]
+        if idx:
             # (zeroed: a mapped file brings no padding up to its 16-byte rounded end along)
             dev = torch.zeros(staged["text_total"], dtype=torch.uint8, device=self.device)
-            idx = sorted(mapped)
             views = [mapped[i][1] for i in idx]
             srcp = (C.c_void_p * len(idx))(*[v.ctypes.data for v in views])
             flags = np.array([1 if mapped[i][2] else 0 for i in idx], dtype=np.uint8)
@@ -340,7 +352,7 @@ class ImageEngine:
                 if st[j]:   # the pages could not be registered: through a pageable copy, once
                     dev[int(offs[i]):int(offs[i]) + views[j].size].copy_(torch.from_numpy(views[j].copy()))
             del views, srcp
-            self._release_mapped(mapped)
+            self._release_mapped(mapped, idx)
             for i in np.flatnonzero(~is_gz):           # the files that could not be mapped lie in the staging buffer
                 if int(i) not in idx and int(staged["disk"][i]):
                     o, nb = int(offs[i]), int(staged["disk"][i])
@@ -354,7 +366,12 @@ class ImageEngine:
             # the compressed bytes are not copied: the inflate kernels read them where they are, in the pinned
             # staging buffer, over PCIe (each byte once by the block-start finder and once by the decoder,
             # ~12 GB/s of a 57 GB/s link) -- 27 ms of H2D copy per 1.5 GB that nothing had to wait for
-            gzdev = pinned[plain_total:stage_total]
+            # ... or, for a rank with few I/O threads, in the files' own page-cache pages (mapped and pinned by stage_files):
+            # every file's address, as an offset from the lowest one
+            addr = np.array([mapped[int(i)][1].ctypes.data if int(i) in mapped else pinned.data_ptr() + int(staged["src"][i])
+                             for i in gi], dtype=np.uint64)
+            gzdev = int(addr.min())
+            rel = addr - np.uint64(gzdev)
             import time
             ti = time.perf_counter()
             # A BGZF file goes in as its members: no member refers to another, so each is a gzip file of its
@@ -362,7 +379,7 @@ class ImageEngine:
             table = staged.get("bgzf") or {}
             go, gl, oo, oc, owner = [], [], [], [], []
             for j, i in enumerate(gi):
-                base = staged["src"][i] - np.uint64(plain_total)
+                base = rel[j]
                 if int(i) in table:
                     mo, ms, mt = table[int(i)]
                     ends = np.cumsum(mt)
@@ -410,7 +427,7 @@ class ImageEngine:
                 except RuntimeError as e:       # no room for that much text: these files fail, the batch lives
                     print("gzip inflate: no memory for", p, "bytes of text:", repr(e)[:120], file=sys.stderr)
                     break
-                g2, s2 = self.inflate(gzdev, staged["src"][oi] - np.uint64(plain_total), staged["disk"][oi], side, o2, c2)
+                g2, s2 = self.inflate(gzdev, rel[over], staged["disk"][oi], side, o2, c2)
                 base = dev.numel()
                 dev = torch.cat([dev, side])
                 del side
@@ -423,7 +440,11 @@ class ImageEngine:
                     print(f"gzip inflate failed (status {int(st[j])}):", staged["paths"][i], file=sys.stderr)
                 else:
                     lens[i] = got[j]
+            if mapped:
+                self._release_mapped(mapped)   # (every inflate call has synchronised)
         torch.cuda.current_stream(self.device).synchronize()
+        if mapped:
+            self._release_mapped(mapped)
         return dev, offs, lens
 
     def upload_files(self, paths, pool=None):
@@ -439,7 +460,8 @@ class ImageEngine:
         oo, oc = self._desc(out_offsets, out_caps)
         lens = np.zeros(n, dtype=np.uint64)
         status = np.zeros(n, dtype=np.uint32)
-        st = self.L.vk_inflate_device(self.ctx, self._ptr(gz), go.ctypes.data_as(C.POINTER(C.c_uint64)),
+        gzp = C.c_void_p(gz) if isinstance(gz, int) else self._ptr(gz)   # (an address: host memory pinned for the GPU)
+        st = self.L.vk_inflate_device(self.ctx, gzp, go.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       gl.ctypes.data_as(C.POINTER(C.c_uint64)), n, self._ptr(out),
                                       oo.ctypes.data_as(C.POINTER(C.c_uint64)), oc.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       lens.ctypes.data_as(C.POINTER(C.c_uint64)),

@@ -79,19 +79,21 @@ def ladder_counts(engine, fastq, offsets, lengths, seed=0, min_bp=50000, max_bp=
             sizes, rec["error"] = [], str(e)
         plans.append(sizes)
         out.append(rec)
-    depth = max((len(p) for p in plans), default=0)
-    for level in range(depth):
-        idx = [i for i in range(n) if len(plans[i]) > level]
-        if level == 0:
-            whole = [i for i in idx if plans[i][0] >= nsites[i]]       # everything: already counted
-            for i in whole:
-                out[i]["steps"].append((plans[i][0], full_hist[i], int(nsites[i])))
-            idx = [i for i in idx if i not in set(whole)]
-        if not idx:
-            continue
-        thr = np.array([threshold(plans[i][level], nsites[i]) for i in idx], dtype=np.uint64)
-        h, _, st = engine.count_sampled(fastq, offsets[idx], lengths[idx], np.uint64(seed + level), thr, parts=parts)
+    # every further step of every sample in ONE launch: a (sample, step) pair is a sample of its own to the kernel
+    # (same bytes, its own seed and threshold); the pairs of a sample run side by side and share its lines in L2
+    pairs = []
+    for i in range(n):
+        for level, bp in enumerate(plans[i]):
+            if level == 0 and bp >= nsites[i]:
+                out[i]["steps"].append((bp, full_hist[i], int(nsites[i])))      # everything: already counted
+            else:
+                pairs.append((i, level))
+    if pairs:
+        idx = [i for i, _ in pairs]
+        thr = np.array([threshold(plans[i][level], nsites[i]) for i, level in pairs], dtype=np.uint64)
+        seeds = np.array([seed + level for _, level in pairs], dtype=np.uint64)
+        h, _, st = engine.count_sampled(fastq, offsets[idx], lengths[idx], seeds, thr, parts=parts)
         taken = st[:, 1].cpu().numpy()
-        for j, i in enumerate(idx):
+        for j, (i, level) in enumerate(pairs):
             out[i]["steps"].append((plans[i][level], h[j], int(taken[j])))
     return out

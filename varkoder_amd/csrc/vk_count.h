@@ -155,12 +155,9 @@ __device__ uint32_t sync_phase(const uint8_t* sbase, uint64_t w0, uint64_t len, 
 
 // reverse the order of the K two-bit groups of a code (no complement)
 __device__ __forceinline__ uint32_t pair_reverse(uint32_t c, int k) {
-    uint32_t x = c;
-    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
-    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
-    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
-    x = (x >> 16) | (x << 16);
-    return x >> (32 - 2 * k);
+    // all 32 bits reversed (one v_bfrev_b32), then the two bits of every group swapped back
+    const uint32_t x = __brev(c);
+    return (((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1)) >> (32 - 2 * k);
 }
 
 // 16 bytes at signed sample offset `off`: zero before the sample and at or beyond `lim`.
@@ -1490,7 +1487,12 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                 }
             }
             // singles: at most a few per lane and piece
+            // (timing diagnostics of pass A, results wrong: -DVK_DIAG_K9_NO_SINGLES, _NO_APPEND, _NO_DRAIN; tools/k9_ab.py)
+#ifdef VK_DIAG_K9_NO_SINGLES
+            uint32_t rem = 0u & one;
+#else
             uint32_t rem = one;
+#endif
             while (__any(rem != 0u)) {
                 if (rem != 0u) {
                     const uint32_t b = vkl::ffbl(rem);                 // 4j
@@ -1563,8 +1565,18 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                     const uint2 e = xg[lz];
                     const uint32_t lo = wave_prev_lane(e.x, xctx);
                     xctx = lane_bcast(e.x, 63);
+#ifdef VK_DIAG_K9_NO_APPEND
+                    asm volatile("" :: "v"(lo), "v"(e.x), "v"(e.y));
+#else
                     append_group(lo, e.x, e.y);
+#endif
+#ifdef VK_DIAG_K9_NO_DRAIN
+                    wave_lds_fence();
+                    if (lane < static_cast<int>(kQueues)) qcnt[lane] = 0u;   // timing only: the queues are thrown away
+                    wave_lds_fence();
+#else
                     maybe_drain(kDrainAt);
+#endif
                 }
                 xpend = tot & 63u;
             }

@@ -800,9 +800,11 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
 
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
-    for (uint32_t i = tid; i < NCODE; i += kCountThreads) {
-        const uint32_t v = hist[i];
-        const uint32_t code = pair_reverse(i, K);  // ABI order: first base most significant
+    // ABI order: first base most significant.  The loop runs over the OUTPUT codes (consecutive threads store
+    // consecutive words) and takes each one's counter from its reversed place in LDS -- the other way round every
+    // wavefront's store touched 64 lines.
+    for (uint32_t code = tid; code < NCODE; code += kCountThreads) {
+        const uint32_t v = hist[pair_reverse(code, K)];
         if (atomic_flush) {
             if (v) atomicAdd(&out[code], v);
         } else {
@@ -1169,9 +1171,8 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
 
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(smp) * NCODE;
-    for (uint32_t i = tid; i < NCODE; i += kCountThreads) {
-        const uint32_t v = hist[i];
-        const uint32_t code = pair_reverse(i, K);
+    for (uint32_t code = tid; code < NCODE; code += kCountThreads) {   // (over the output codes, as in vk_count_kernel)
+        const uint32_t v = hist[pair_reverse(code, K)];
         if (atomic_flush) {
             if (v) atomicAdd(&out[code], v);
         } else {

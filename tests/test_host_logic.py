@@ -245,6 +245,18 @@ def test_stage_files_survives_an_unreadable_file(tmp_path, monkeypatch):
     assert st["offs"][0] >= st["plain_total"] and st["text_total"] % 16 == 0
 
 
+def test_plain_route_follows_the_rank_s_io_threads(monkeypatch):
+    """engine.plain_route: files come in by DMA from the page cache where a rank has few I/O threads (several ranks
+    on one host's cores), through the staging buffer where it has 16 or more; VARKODER_AMD_MMAP forces either."""
+    from varkoder_amd import engine as engine_mod
+    monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", None)
+    assert [engine_mod.plain_route(t) for t in (1, 2, 8, 15, 16, 64)] == ["mapped"] * 4 + ["staged"] * 2
+    monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", True)
+    assert engine_mod.plain_route(64) == "mapped"
+    monkeypatch.setattr(engine_mod, "USE_MAPPED_UPLOAD", False)
+    assert engine_mod.plain_route(1) == "staged"
+
+
 def test_bgzf_text_size_walks_block_headers():
     """engine.bgzf_text_size: the text size of a BGZF file without inflating it; None for anything else."""
     import gzip

@@ -151,6 +151,20 @@ int vk_image_host(vk_ctx* ctx, const uint32_t* hist, int k, uint8_t* img);
 int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t nsamples,
                           uint32_t reads, uint32_t readlen, uint64_t seed, int dist);
 
+/* Synthetic FASTQ shaped like the files step B of the reference hands to step D: fastp runs with --merge
+ * --include_unmerged and --disable_length_filtering (commands/image.py:405,426-427,494-495), so a cleaned file
+ * holds reads of every length from 0 to about 2 x readlen under long headers.  Per read: 65 % readlen bases,
+ * 20 % merged pairs (readlen+1 .. 2*readlen-10), 10 % trimmed (45 .. readlen-1), 5 % of 0 .. 44 bases (empty
+ * reads included); header lines of 40 .. 70 bytes; quality characters '!' .. 'I' ('@' and '+' among them).
+ * Samples differ in size: vk_synth_shaped_lengths fills lengths[nsamples] (host; synchronises), the caller lays
+ * the samples out at 16-byte aligned offsets[] and vk_synth_shaped_device writes them (bytes up to each
+ * sample's 16-byte rounded end are zeroed; synchronises).  64 <= readlen <= 1000.
+ * varkoder_amd/synth.py (dist=2) is the bit-identical host generator. */
+int vk_synth_shaped_lengths(vk_ctx* ctx, uint32_t sample0, uint32_t nsamples, uint32_t reads, uint32_t readlen,
+                            uint64_t seed, uint64_t* lengths);
+int vk_synth_shaped_device(vk_ctx* ctx, void* d_out, const uint64_t* offsets, uint32_t sample0, uint32_t nsamples,
+                           uint32_t reads, uint32_t readlen, uint64_t seed);
+
 /* Replaces remap() of `varKoder convert` (commands/convert.py:34-77) for a batch of host
  * images: out[p] = in[src0[p]] (src 0xFFFFFFFF = pixel without a k-mer -> 0); with sum_rc the
  * uint8-wrapping sum w0[p]*in[src0[p]] + w1[p]*in[src1[p]] followed by the reference's
@@ -189,6 +203,11 @@ int vk_host_unregister(vk_ctx* ctx, const void* p);
 /* Introspection used by bench.py / tests: workgroups and LDS bytes of the last
  * vk_count_device launch. */
 int vk_last_count_launch(const vk_ctx* ctx, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes);
+
+/* Introspection (bench.py): of the last vk_count_device call with k <= 7, how many 4 KiB pieces of text left the
+ * sequence-only fast path for the general one (reads under ~45 bases, non-ASCII bytes, low complexity, the first
+ * and last piece of every wavefront's range), and about how many pieces there were.  Synchronises. */
+int vk_last_count_general(vk_ctx* ctx, uint64_t* general_pieces, uint64_t* pieces);
 
 #ifdef __cplusplus
 }

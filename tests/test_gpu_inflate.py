@@ -446,3 +446,23 @@ def test_inflate_verifies_every_member_of_many_member_files(engines, tmp_path):
         dev, offs, lens = eng.upload_files(names)
         assert [int(x) for x in lens] == [len(large), 0, 0]
         assert bytes(dev.cpu().numpy()[int(offs[0]):int(offs[0]) + len(large)]) == large
+
+
+def test_overflow_retries_never_shrink_the_slot_and_mapped_files_are_released(engines, tmp_path, monkeypatch):
+    """A small, highly compressible file whose size word lies (two members: the slot is sized for the last one
+    alone) overflows its first slot; the retry must be larger than that slot (32x the file was below
+    the 64x first slot), and the text must come out whole.  Also through the mapped route, whose pinned pages are
+    released whatever happens."""
+    from varkoder_amd import engine as E
+    eng = engines(7)
+    a = (b"@r\n" + b"A" * 150 + b"\n+\n" + b"I" * 150 + b"\n") * 4000        # 1.2 MB of text, compresses ~200x
+    b = b"@q\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    blob = gz(a, 9) + gz(b, 9)                                                # ISIZE of the file = len(b)
+    f = tmp_path / "two.fq.gz"
+    f.write_bytes(blob)
+    for route in ("0", "1"):
+        monkeypatch.setattr(E, "USE_MAPPED_UPLOAD", route == "1")
+        dev, offs, lens = eng.upload_files([f])
+        assert int(lens[0]) == len(a) + len(b), route
+        assert bytes(dev.cpu().numpy()[int(offs[0]):int(offs[0]) + int(lens[0])]) == a + b, route
+        assert int(eng.last_upload_status[0]) == 0

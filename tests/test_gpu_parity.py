@@ -42,10 +42,11 @@ def test_count_edge_cases_match_oracle(engines, k):
 
 
 @pytest.mark.parametrize("k", KS)
-@pytest.mark.parametrize("dist", (0, 1))
+@pytest.mark.parametrize("dist", (0, 1, 2))
 def test_count_synthetic_batch_matches_oracle(engines, k, dist):
     """Small parity set of SURVEY 8d: 8 samples x 10,000 reads x 150 bp, generated on the
-    host, counted in one batched launch (several workgroup splits)."""
+    host, counted in one batched launch (several workgroup splits).  dist 2: reads of every length
+    from 0 to 290 under long headers, as fastp hands them to step D (synth.py)."""
     eng = engines(k)
     samples = [synth.sample_fastq(s, 10000, 150, dist=dist) for s in range(8)]
     dev, offs, lens = eng.upload(samples)
@@ -59,13 +60,22 @@ def test_count_synthetic_batch_matches_oracle(engines, k, dist):
 
 def test_device_generator_equals_host_generator(engines):
     eng = engines(7)
-    for dist in (0, 1):
+    for dist in (0, 1, 2):
         dev, offs, lens = eng.synth(5, 3, 2000, 150, dist=dist)
         got = dev.cpu().numpy()
         for j in range(3):
             want = synth.sample_fastq(5 + j, 2000, 150, dist=dist)
             o = int(offs[j])
+            assert int(lens[j]) == want.size, (dist, j)
             assert np.array_equal(got[o:o + want.size], want), (dist, j)
+    # dist 2 across the generator's slabs of 64 samples and chunks of 256 reads, padding zeroed
+    dev, offs, lens = eng.synth(60, 70, 700, 150, dist=2)
+    got = dev.cpu().numpy()
+    for j in (0, 63, 64, 69):
+        want = synth.sample_fastq(60 + j, 700, 150, dist=2)
+        o = int(offs[j])
+        assert int(lens[j]) == want.size and np.array_equal(got[o:o + want.size], want), j
+        assert not got[o + want.size:(o + want.size + 15) // 16 * 16].any(), j
 
 
 @pytest.mark.parametrize("k", KS)
@@ -157,6 +167,29 @@ def test_full_size_samples_match_oracle(engines, k, mapping):
     cs = torch.cat([torch.zeros((reads, 1), dtype=cs.dtype, device=cs.device), cs], dim=1)
     clean = ((cs[:, k:] - cs[:, :-k]) == 0).sum().item()
     assert clean == nwins[0]
+
+
+@pytest.mark.parametrize("k,mapping", [(7, "varKode"), (9, "cgr")])
+def test_full_size_fastp_shaped_sample_matches_oracle(engines, k, mapping):
+    """One sample of 1,000,000 reads of the lengths fastp really writes (0 .. 290 bases, 40 .. 70 byte headers,
+    '@' and '+' in the quality lines; synth.py dist 2), 364 MB of text: histogram and image bit-identical."""
+    eng = engines(k, mapping)
+    dev, offs, lens = eng.synth(950, 1, 1_000_000, 150, dist=2)
+    host = dev.cpu().numpy()[:int(lens[0])]
+    lut, n = pixel_lut(k, mapping), side(k, mapping)
+    want_h, nwin, st = oracle.count_fastq(host, k)
+    assert st == 0
+    want_i = oracle.image(oracle.strand_merge(want_h, k), k, lut, n * n)
+    for parts in (0, 3):
+        img, hist, status = eng.fastq_to_images(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got_h = hist.cpu().numpy().view(np.uint32)[0]
+        assert int(got_h.sum(dtype=np.uint64)) == nwin
+        assert np.array_equal(got_h, want_h), parts
+        assert np.array_equal(img.cpu().numpy()[0].ravel(), want_i), parts
+    if k <= 7:
+        general, pieces = eng.last_count_general()
+        assert 0 < general <= pieces
 
 
 @pytest.mark.parametrize("k", (8, 9))

@@ -280,3 +280,44 @@ def test_bgzf_text_size_walks_block_headers():
     assert bgzf_text_size(np.frombuffer(blob, dtype=np.uint8)) == len(data)
     assert bgzf_text_size(gzip.compress(data)) is None          # one ordinary member: its own size word is right
     assert bgzf_text_size(blob + b"junk") is None and bgzf_text_size(blob[:-5]) is None and bgzf_text_size(b"") is None
+
+
+def test_fastp_shaped_generator_writes_well_formed_fastq():
+    """synth.py dist 2 (what bench.py's `realistic` legs and the GPU parity tests count): four-line records,
+    sequence and quality of equal length, lengths over the whole range, the oracle accepts it."""
+    from oracle import oracle
+    from varkoder_amd import synth
+    fq = synth.sample_fastq(11, 3000, 150, dist=2)
+    hl, ln, off = synth.shaped_layout(11, 3000, 150)
+    assert fq.size == off[-1] and (hl >= 40).all() and (hl <= 70).all()
+    assert ln.min() == 0 and ln.max() > 250 and 0.55 < (ln == 150).mean() < 0.75 and (ln < 45).mean() > 0.02
+    lines = fq.tobytes().split(b"\n")
+    assert lines[-1] == b"" and (len(lines) - 1) == 4 * 3000
+    for r in range(3000):
+        h, s, p, q = lines[4 * r:4 * r + 4]
+        assert h.startswith(b"@s00011.%07d " % r) and len(h) + 1 == hl[r]
+        assert len(s) == len(q) == ln[r] and p == b"+" and set(s) <= set(b"ACGTN")
+    assert any(l[3][:1] == b"@" for l in zip(*[iter(lines[:-1])] * 4))      # a quality line that starts with '@'
+    hist, nwin, st = oracle.count_fastq(fq, 7)
+    assert st == 0 and nwin == int(hist.sum())
+
+
+def test_bgzf_table_refuses_blocks_that_claim_more_than_64k_of_text():
+    """A BGZF-looking file whose members claim gigabytes of text must not size the text slot: the
+    member table is dropped and the file goes the ordinary way, whose slot is clamped against its size on disk."""
+    import struct
+    import zlib
+    from varkoder_amd.engine import bgzf_members
+
+    def block(payload, isize=None):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(payload) + co.flush()
+        size = 12 + 6 + len(body) + 8
+        hdr = b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1)
+        return hdr + body + struct.pack("<II", zlib.crc32(payload), len(payload) if isize is None else isize)
+
+    good = block(b"@r\nACGT\n+\nIIII\n") + block(b"")
+    m = bgzf_members(np.frombuffer(good, dtype=np.uint8))
+    assert m is not None and int(m[2].sum()) == 15
+    hostile = block(b"@r\nACGT\n+\nIIII\n", isize=0xFFFFFF00) + block(b"")
+    assert bgzf_members(np.frombuffer(hostile, dtype=np.uint8)) is None

@@ -110,3 +110,42 @@ def test_dsk_shim_fails_like_check_true_on_broken_framing(tmp_path, tool_argv):
     r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not counts.exists()
     assert "framing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_dsk_shim_takes_an_empty_text_gz_and_rejects_a_damaged_one(tmp_path, tool_argv):
+    """The shim reads through the engine's mapped route (one I/O thread): a valid .gz whose text is empty is a
+    sample without k-mers (dsk would write an empty table), not an unreadable file; a damaged .gz is an error."""
+    import gzip
+    k = tool_argv["k"]
+    dsk, d2a = tool_argv["calls"]
+    empty = tmp_path / "E@00000001K.fq.gz"
+    empty.write_bytes(gzip.compress(b""))
+    counts = tmp_path / f"E@00000001K+k{k}.fq.h5"
+    a = _fill(dsk, IN=str(empty), TMP=str(tmp_path), COUNTS=str(counts))
+    r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and counts.exists(), r.stderr
+    a = _fill(d2a, TMP=str(tmp_path), COUNTS=str(counts))
+    r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == ""
+    # a real .gz through the same (mapped) route
+    data = fastq_cases.edge_cases()["mixed_case_iupac"]
+    good = tmp_path / "G@00000001K.fq.gz"
+    good.write_bytes(gzip.compress(data))
+    counts = tmp_path / f"G@00000001K+k{k}.fq.h5"
+    a = _fill(dsk, IN=str(good), TMP=str(tmp_path), COUNTS=str(counts))
+    r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a = _fill(d2a, TMP=str(tmp_path), COUNTS=str(counts))
+    r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
+    _, _, want = formats.class_counts(oracle.count_fastq(data, k)[0], k)
+    assert np.array_equal(formats.parse_dsk_text(r.stdout, k), want)
+    # damaged: the shim fails like `check=True` would see dsk fail
+    bad = tmp_path / "B@00000001K.fq.gz"
+    blob = bytearray(gzip.compress(data * 20))
+    blob[len(blob) // 2] ^= 0xFF
+    bad.write_bytes(bytes(blob))
+    counts = tmp_path / f"B@00000001K+k{k}.fq.h5"
+    a = _fill(dsk, IN=str(bad), TMP=str(tmp_path), COUNTS=str(counts))
+    r = subprocess.run([os.path.join(shims.BIN_DIR, a[0])] + a[1:], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not counts.exists()

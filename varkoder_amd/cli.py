@@ -145,88 +145,112 @@ def run_query(args):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)        # control plane only
-    mine = shard_indices(len(inputs), rank, world)
-    model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
-    records, images, order = [], None, []   # order: index of each record's input in `inputs`
-    eng = None
-    if args.images:
-        arrays = []
-        for i in mine:
-            p = inputs[i]
-            im = Image.open(p)
-            md = get_metadata_from_img_filename(p)
-            labels, qual, sd = Q.image_metadata(im.info)
-            records.append(dict(path=str(p), sample=md["sample"], bp=md["bp"], k=md["img_kmer_size"],
-                                mapping=md["img_kmer_mapping"], labels=labels, qual=qual, freq_sd=sd))
-            arrays.append(np.array(im))
-            order.append(i)
-        shapes = {a.shape for a in arrays}
-        if len(shapes) > 1:
-            raise Exception("Images of different sizes in one query are not supported.")
-        if arrays:
-            eng = ImageEngine(k=records[0]["k"], mapping="cgr", device=device)
-            images = torch.from_numpy(np.stack(arrays)).to(eng.device)
-    else:
-        max_bp = None if str(args.max_bp) == "0" else parse_size(args.max_bp)
-        rng = np.random.default_rng(args.seed)
-        # one seed per sample in input order, as image.py:1017 -- drawn for every input on every rank
-        seeds = [int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63) for i in range(len(inputs))]
-        hists, keep = [], []
-        if mine:
-            eng = ImageEngine(k=args.kmer_size, mapping=args.kmer_mapping, device=device)
-            files = [inputs[i] for i in mine]
-            dev, offs, lens = eng.upload_files(files)
-            for j, (i, f) in enumerate(zip(mine, files)):
-                sample = str(f.name.removesuffix("".join(f.suffixes)))
-                rec = ladder_counts(eng, dev, offs[j:j + 1], lens[j:j + 1], seed=seeds[i], max_bp=max_bp, is_query=True)[0]
-                if rec["error"] or not rec["steps"]:
-                    eprint("SPLIT FAIL:", f, "-", rec["error"])
-                    continue
-                bp, hist, _ = rec["steps"][0]
-                name = split_name(sample, bp) + f"+{args.kmer_mapping}+k{args.kmer_size}.png"
-                path = str(outdir / "query_images" / name) if args.keep_images else name
-                records.append(dict(path=path, sample=sample, bp=int(bp / 1000) * 1000, k=args.kmer_size,
-                                    mapping=args.kmer_mapping, labels="", qual=bool("False"), freq_sd=0.0))
-                hists.append(hist)
-                keep.append(name)
+    # A rank that fails must not leave the others waiting in the gather: its work runs inside one try block, the
+    # error travels WITH the gathered results, and every rank -- failed or not -- takes part in the gather and the
+    # closing barrier; the exception is raised after the process group is gone.
+    state = {"eng": None}
+    model = vocab = None
+
+    def rank_work():
+        nonlocal model, vocab
+        mine = shard_indices(len(inputs), rank, world)
+        model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
+        records, images, order = [], None, []   # order: index of each record's input in `inputs`
+        eng = None
+        if args.images:
+            arrays = []
+            for i in mine:
+                p = inputs[i]
+                im = Image.open(p)
+                md = get_metadata_from_img_filename(p)
+                labels, qual, sd = Q.image_metadata(im.info)
+                records.append(dict(path=str(p), sample=md["sample"], bp=md["bp"], k=md["img_kmer_size"],
+                                    mapping=md["img_kmer_mapping"], labels=labels, qual=qual, freq_sd=sd))
+                arrays.append(np.array(im))
                 order.append(i)
-            if hists:
-                images = eng.images(torch.stack(hists))
-                if args.keep_images:
-                    (outdir / "query_images").mkdir(parents=True, exist_ok=True)
-                    host = images.cpu().numpy()
-                    for j, name in enumerate(keep):
-                        write_png(host[j], outdir / "query_images" / name, [], 0, QUAL_THRESH, args.kmer_mapping)
-    if rank == 0:
-        if args.single_label:
-            eprint("This is a single label classification model, each input may will have only one prediction.")
+            shapes = {a.shape for a in arrays}
+            if len(shapes) > 1:
+                raise Exception("Images of different sizes in one query are not supported.")
+            if arrays:
+                eng = state["eng"] = ImageEngine(k=records[0]["k"], mapping="cgr", device=device)
+                images = torch.from_numpy(np.stack(arrays)).to(eng.device)
         else:
-            eprint("This is a multilabel classification model, each input may have 0 or more predictions.")
-    probs = None
-    if images is not None:
-        probs = Q.probabilities(eng, images, model, batch_size=args.max_batch_size, multilabel=not args.single_label,
-                                input_size=args.input_size, half=args.half)
-    parts = [(order, records, None if probs is None else np.asarray(probs))]
+            max_bp = None if str(args.max_bp) == "0" else parse_size(args.max_bp)
+            rng = np.random.default_rng(args.seed)
+            # one seed per sample in input order, as image.py:1017 -- drawn for every input on every rank
+            seeds = [int(str(i) + str(rng.integers(low=0, high=2 ** 32))) % (1 << 63) for i in range(len(inputs))]
+            hists, keep = [], []
+            if mine:
+                eng = state["eng"] = ImageEngine(k=args.kmer_size, mapping=args.kmer_mapping, device=device)
+                files = [inputs[i] for i in mine]
+                dev, offs, lens = eng.upload_files(files)
+                for j, (i, f) in enumerate(zip(mine, files)):
+                    sample = str(f.name.removesuffix("".join(f.suffixes)))
+                    rec = ladder_counts(eng, dev, offs[j:j + 1], lens[j:j + 1], seed=seeds[i], max_bp=max_bp, is_query=True)[0]
+                    if rec["error"] or not rec["steps"]:
+                        eprint("SPLIT FAIL:", f, "-", rec["error"])
+                        continue
+                    bp, hist, _ = rec["steps"][0]
+                    name = split_name(sample, bp) + f"+{args.kmer_mapping}+k{args.kmer_size}.png"
+                    path = str(outdir / "query_images" / name) if args.keep_images else name
+                    records.append(dict(path=path, sample=sample, bp=int(bp / 1000) * 1000, k=args.kmer_size,
+                                        mapping=args.kmer_mapping, labels="", qual=bool("False"), freq_sd=0.0))
+                    hists.append(hist)
+                    keep.append(name)
+                    order.append(i)
+                if hists:
+                    images = eng.images(torch.stack(hists))
+                    if args.keep_images:
+                        (outdir / "query_images").mkdir(parents=True, exist_ok=True)
+                        host = images.cpu().numpy()
+                        for j, name in enumerate(keep):
+                            write_png(host[j], outdir / "query_images" / name, [], 0, QUAL_THRESH, args.kmer_mapping)
+        if rank == 0:
+            if args.single_label:
+                eprint("This is a single label classification model, each input may will have only one prediction.")
+            else:
+                eprint("This is a multilabel classification model, each input may have 0 or more predictions.")
+        probs = None
+        if images is not None:
+            probs = Q.probabilities(eng, images, model, batch_size=args.max_batch_size, multilabel=not args.single_label,
+                                    input_size=args.input_size, half=args.half)
+        return order, records, None if probs is None else np.asarray(probs)
+
+    failure = None
+    try:
+        part = rank_work() + (None,)
+    except Exception as e:   # noqa: BLE001 -- reported below, once every rank is past its collectives
+        failure = e
+        part = ([], [], None, "rank %d: %r" % (rank, e))
+    parts = [part]
     if world > 1:
         import torch.distributed as dist
         bucket = [None] * world if rank == 0 else None
-        dist.gather_object(parts[0], bucket, dst=0)
+        dist.gather_object(part, bucket, dst=0)
         parts = bucket if rank == 0 else []
     if rank == 0:
-        rows = sorted(((i, r, p) for o, rs, ps in parts if ps is not None for i, r, p in zip(o, rs, ps)), key=lambda t: t[0])
-        if not rows:
-            raise Exception("No images found to query. Please check your input.")
-        df = Q.predictions_frame([r for _, r, _ in rows], np.stack([p for _, _, p in rows]), vocab, args.model,
-                                 args.threshold, not args.single_label, args.include_probs)
-        outdir.mkdir(parents=True, exist_ok=True)
-        df.to_csv(outdir / "predictions.csv", index=False)
-        eprint("Predictions saved to", str(outdir / "predictions.csv"))
-    if eng is not None:
-        eng.close()
+        errors = [e for _, _, _, e in parts if e]
+        try:
+            if errors:
+                raise failure if failure is not None else Exception("query failed on " + "; ".join(errors))
+            rows = sorted(((i, r, p) for o, rs, ps, _ in parts if ps is not None for i, r, p in zip(o, rs, ps)), key=lambda t: t[0])
+            if not rows:
+                raise Exception("No images found to query. Please check your input.")
+            df = Q.predictions_frame([r for _, r, _ in rows], np.stack([p for _, _, p in rows]), vocab, args.model,
+                                     args.threshold, not args.single_label, args.include_probs)
+            outdir.mkdir(parents=True, exist_ok=True)
+            df.to_csv(outdir / "predictions.csv", index=False)
+            eprint("Predictions saved to", str(outdir / "predictions.csv"))
+        except Exception as e:   # noqa: BLE001
+            failure = e
+    if state["eng"] is not None:
+        state["eng"].close()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if failure is not None:
+        raise failure
 
 
 def read_labels(path):

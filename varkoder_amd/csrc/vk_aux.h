@@ -91,6 +91,127 @@ __global__ void vk_synth_kernel(uint8_t* __restrict__ out, uint32_t sample0, uin
     }
 }
 
+// ---- dist 2: reads shaped like what step B of the reference hands to step D -------------------------
+// fastp runs with --merge --include_unmerged and --disable_length_filtering (commands/image.py:405,426-427,
+// 494-495): the files step D counts hold reads of every length from 0 to about twice the read length under
+// long headers.  Per read (key stream 5): 65 % readlen bases, 20 % merged pairs of readlen+1 .. 2*readlen-10,
+// 10 % trimmed reads of 45 .. readlen-1, 5 % of 0 .. 44 (empty ones included); header lines of 40 .. 70
+// bytes; quality characters '!' .. 'I' (so '@' and '+' occur in them, also first in the line).  Bases as
+// dist 0 (uniform, N at ~1e-3).  varkoder_amd/synth.py is the bit-identical host generator.
+struct SynthRead {
+    uint32_t hl;   // bytes of the header line, its newline included
+    uint32_t len;  // bases
+};
+
+__device__ __host__ inline SynthRead synth_read_shape(uint64_t seed, uint32_t s, uint32_t r, uint32_t readlen) {
+    const uint64_t h = vk_mix(seed, s, r, 0, 5);
+    const uint32_t u = static_cast<uint32_t>(h % 100u), v = static_cast<uint32_t>((h >> 8) & 0xFFFFFFu);
+    SynthRead o;
+    o.len = u < 65u ? readlen : (u < 85u ? readlen + 1u + v % (readlen - 10u) : (u < 95u ? 45u + v % (readlen - 45u) : v % 45u));
+    o.hl = 40u + static_cast<uint32_t>((h >> 40) % 31u);
+    return o;
+}
+
+__device__ __host__ inline uint32_t synth_record_bytes(const SynthRead& sr) { return sr.hl + 2u * sr.len + 4u; }
+
+// per sample: exclusive prefix sums of the record sizes, recoff[sample][0 .. reads] (u32: a sample stays below 4 GiB)
+__global__ __launch_bounds__(1024) void vk_synth_shape_kernel(uint32_t* __restrict__ recoff, uint32_t sample0, uint32_t reads,
+                                                              uint32_t readlen, uint64_t seed) {
+    __shared__ uint32_t part[1024];
+    const uint32_t s = sample0 + blockIdx.x, tid = threadIdx.x;
+    const uint32_t per = (reads + 1023u) / 1024u;
+    const uint32_t r0 = tid * per < reads ? tid * per : reads, r1 = r0 + per < reads ? r0 + per : reads;
+    uint32_t sum = 0;
+    for (uint32_t r = r0; r < r1; ++r) sum += synth_record_bytes(synth_read_shape(seed, s, r, readlen));
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {   // inclusive scan of the threads' sums
+        const uint32_t add = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t at = part[tid] - sum;
+    uint32_t* out = recoff + static_cast<uint64_t>(blockIdx.x) * (reads + 1u);
+    for (uint32_t r = r0; r < r1; ++r) {
+        out[r] = at;
+        at += synth_record_bytes(synth_read_shape(seed, s, r, readlen));
+    }
+    if (tid == 1023u) out[reads] = part[1023];
+}
+
+__device__ inline uint8_t synth_shaped_byte(uint64_t seed, uint32_t s, uint32_t r, uint32_t off, const SynthRead& sr) {
+    if (off < sr.hl) {
+        if (off == 0) return '@';
+        if (off == 1) return 's';
+        if (off < 7) {
+            uint32_t p10 = 1;
+            for (uint32_t e = 0; e < 6 - off; ++e) p10 *= 10;
+            return static_cast<uint8_t>('0' + (s / p10) % 10);
+        }
+        if (off == 7) return '.';
+        if (off < 15) {
+            uint32_t p10 = 1;
+            for (uint32_t e = 0; e < 14 - off; ++e) p10 *= 10;
+            return static_cast<uint8_t>('0' + (r / p10) % 10);
+        }
+        if (off == sr.hl - 1u) return '\n';
+        if (off == 15) return ' ';
+        return static_cast<uint8_t>("ABCDEFGHIJKLMNOPQRSTUVWXYZ:_/=0123456789"[(off + r) % 40u]);
+    }
+    off -= sr.hl;
+    if (off < sr.len) return synth_base(seed, s, r, off, sr.len, 0);
+    off -= sr.len;
+    if (off == 0) return '\n';
+    if (off == 1) return '+';
+    if (off == 2) return '\n';
+    off -= 3;
+    if (off < sr.len) return static_cast<uint8_t>(33u + static_cast<uint32_t>((vk_mix(seed, s, r, off >> 3, 6) >> (8u * (off & 7u))) & 0xFFu) % 41u);
+    return '\n';
+}
+
+// one workgroup per (sample, 256 reads): the 16-byte granules whose FIRST byte lies in those reads
+__global__ __launch_bounds__(256) void vk_synth_shaped_kernel(uint8_t* __restrict__ out, const uint64_t* __restrict__ soffs,
+                                                              const uint32_t* __restrict__ recoff, uint32_t sample0,
+                                                              uint32_t reads, uint32_t readlen, uint64_t seed) {
+    __shared__ uint32_t off[258];
+    const uint32_t chunks = (reads + 255u) / 256u;
+    const uint32_t sl = blockIdx.x / chunks, c = blockIdx.x % chunks, s = sample0 + sl;
+    const uint32_t r0 = c * 256u;
+    const uint32_t* ro = recoff + static_cast<uint64_t>(sl) * (reads + 1u);
+    const uint32_t total = ro[reads];
+    for (uint32_t i = threadIdx.x; i < 258u; i += 256u) off[i] = r0 + i <= reads ? ro[r0 + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t nr = reads - r0 < 256u ? reads - r0 : 256u;      // reads of this chunk
+    const uint32_t b0 = off[0], b1 = off[nr];                       // its bytes
+    const uint32_t end = c + 1u == chunks ? (total + 15u) / 16u * 16u : b1;   // the last chunk pads the sample with zeros
+    uint8_t* dst = out + soffs[sl];
+    for (uint32_t g = (b0 + 15u) / 16u + threadIdx.x; g * 16u < end; g += 256u) {
+        const uint32_t o0 = g * 16u;
+        uint32_t lo = 0, hi = nr + 1u;   // the read (0 .. nr: one beyond the chunk may be reached) that holds byte o0
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= o0) lo = mid; else hi = mid;
+        }
+        uint32_t ri = lo;
+        SynthRead sr = synth_read_shape(seed, s, r0 + ri, readlen);
+        uint8_t bytes[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t o = o0 + t;
+            if (o >= total) { bytes[t] = 0; continue; }
+            if (o >= off[ri + 1u]) {   // (records are longer than 16 bytes: one step at most)
+                ++ri;
+                sr = synth_read_shape(seed, s, r0 + ri, readlen);
+            }
+            bytes[t] = synth_shaped_byte(seed, s, r0 + ri, o - off[ri], sr);
+        }
+        uint4 v;
+        memcpy(&v, bytes, 16);
+        *reinterpret_cast<uint4*>(dst + o0) = v;
+    }
+}
+
 // ----------------------------------------------------------------- remap ----
 // convert.py:34-77 as a gather: out[p] = in[src0[p]] (0xFFFFFFFF = unmapped -> 0), or with
 // sum_rc the uint8-wrapping weighted sum of two source pixels followed by the reference's

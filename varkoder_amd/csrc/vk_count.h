@@ -976,7 +976,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     __syncthreads();
 
     const WaveRange wr = wave_range(lens[smp], parts, part, wave);
-    uint32_t ph_start = 0, ph_end = 0;
+    uint32_t ph_start = 0, ph_end = 0, general_pieces = 0;
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         uint32_t npend = 0;   // granules waiting in xb[0 .. npend), < 64 between pieces
         bool hot = false;
         uint32_t tick = 0;    // calls of the low-complexity probe
+        uint32_t ngeneral = 0;  // pieces that took the general path (reported in the wave's phase word, bits 8..31)
 
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
@@ -1094,6 +1095,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
                 // classified at once -- would spill the fast path's loop invariants) ----
                 if (npend != 0u) flush();
+                ++ngeneral;
                 GeneralState gs;
                 gs.ctx_c = ctx_c; gs.ctx_bad = ctx_bad; gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
                 gs = general_piece<K>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u), ph0,
@@ -1158,6 +1160,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             pph += total;
         }
         ph_end = pph & 3u;
+        general_pieces = ngeneral < 0xFFFFFFu ? ngeneral : 0xFFFFFFu;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
 #ifdef VK_STAMPS
         if (lane == 0 && (blockIdx.x & 63u) == 0u) {  // [5] wait for the piece's bytes, [6] whole iterations, [7] pieces
@@ -1167,7 +1170,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         }
 #endif
     }
-    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2) | (general_pieces << 8));
 
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(smp) * NCODE;

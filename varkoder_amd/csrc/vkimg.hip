@@ -85,10 +85,15 @@ struct vk_ctx {
     size_t sub_cap = 0;
     uint8_t* d_stage = nullptr;
     size_t stage_cap = 0;
+    uint32_t* d_synth = nullptr;       // vk_synth_shaped_*: record offsets of a slab of samples
+    size_t synth_cap = 0;
+    uint64_t* d_synth_offs = nullptr;  // ... and the slab's sample offsets
+    size_t synth_offs_cap = 0;
     uint32_t* d_hist1 = nullptr;
     uint32_t* d_status1 = nullptr;
     uint8_t* d_img1 = nullptr;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+    uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
     bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
@@ -344,7 +349,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc, ctx->d_synth, ctx->d_synth_offs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -363,6 +368,7 @@ int vk_ctx_sync(vk_ctx* ctx) {
 
 int vk_host_register(vk_ctx* ctx, const void* p, uint64_t nbytes) {
     if (!ctx || !p || nbytes == 0) return VK_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return VK_EHIP;   // (the calling thread may be an I/O thread that never chose a device)
     const hipError_t e = hipHostRegister(const_cast<void*>(p), nbytes, hipHostRegisterDefault);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -373,12 +379,14 @@ int vk_host_register(vk_ctx* ctx, const void* p, uint64_t nbytes) {
 
 int vk_host_unregister(vk_ctx* ctx, const void* p) {
     if (!ctx || !p) return VK_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return VK_EHIP;
     return hipHostUnregister(const_cast<void*>(p)) == hipSuccess ? VK_OK : VK_EHIP;
 }
 
 int vk_upload_mapped(vk_ctx* ctx, void* d_dst, const uint64_t* dst_offsets, const void* const* h_src,
                      const uint64_t* nbytes, const uint8_t* registered, uint32_t nfiles, uint32_t* status) {
     if (!ctx || !d_dst || (nfiles && (!dst_offsets || !h_src || !nbytes || !status))) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<char> reg(nfiles, 0), mine(nfiles, 0);
     auto pin = [&](uint32_t i) {   // the file's page-cache pages, pinned and mapped for the DMA engines
         status[i] = 0u;
@@ -495,6 +503,9 @@ static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
         default: rc = launch_spill<9>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, sub); break;
     }
     if (rc) return rc;
+    ctx->last_waves = static_cast<uint64_t>(nsamples) * parts * kWaves;
+    ctx->last_bytes = 0;
+    for (uint32_t i = 0; i < nsamples; ++i) ctx->last_bytes += lengths[i];
     hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, d_offs, d_lens,
                        nsamples, parts, ctx->d_wavephase, d_status);
     VK_HIP(ctx, hipGetLastError());
@@ -922,6 +933,61 @@ int vk_synth_fastq_device(vk_ctx* ctx, void* d_out, uint32_t sample0, uint32_t n
     return VK_OK;
 }
 
+// dist 2 (vk_aux.h, "reads shaped like what step B hands to step D"): the record offsets of `n` samples in the
+// context's workspace, n * (reads + 1) u32
+static int synth_shapes(vk_ctx* ctx, uint32_t sample0, uint32_t n, uint32_t reads, uint32_t readlen, uint64_t seed) {
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_synth), &ctx->synth_cap, static_cast<size_t>(n) * (reads + 1ull) * sizeof(uint32_t));
+    if (rc) return rc;
+    hipLaunchKernelGGL(vk_synth_shape_kernel, dim3(n), dim3(1024), 0, ctx->stream, ctx->d_synth, sample0, reads, readlen, seed);
+    VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_synth_shaped_lengths(vk_ctx* ctx, uint32_t sample0, uint32_t nsamples, uint32_t reads, uint32_t readlen,
+                            uint64_t seed, uint64_t* lengths) {
+    if (!ctx || !lengths || readlen < 64 || readlen > 1000 || reads == 0 || reads > 4000000u) return VK_EINVAL;
+    if (static_cast<uint64_t>(reads) * (74ull + 4ull * readlen) >= (1ull << 32)) return VK_EINVAL;   // record offsets are u32
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t kSlab = 64;
+    std::vector<uint32_t> tot(kSlab);
+    for (uint32_t s0 = 0; s0 < nsamples; s0 += kSlab) {
+        const uint32_t n = nsamples - s0 < kSlab ? nsamples - s0 : kSlab;
+        int rc = synth_shapes(ctx, sample0 + s0, n, reads, readlen, seed);
+        if (rc) return rc;
+        VK_HIP(ctx, hipMemcpy2DAsync(tot.data(), sizeof(uint32_t), ctx->d_synth + reads, (reads + 1ull) * sizeof(uint32_t),
+                                     sizeof(uint32_t), n, hipMemcpyDeviceToHost, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < n; ++i) lengths[s0 + i] = tot[i];
+    }
+    return VK_OK;
+}
+
+int vk_synth_shaped_device(vk_ctx* ctx, void* d_out, const uint64_t* offsets, uint32_t sample0, uint32_t nsamples,
+                           uint32_t reads, uint32_t readlen, uint64_t seed) {
+    if (!ctx || !d_out || !offsets || readlen < 64 || readlen > 1000 || reads == 0 || reads > 4000000u) return VK_EINVAL;
+    if (static_cast<uint64_t>(reads) * (74ull + 4ull * readlen) >= (1ull << 32)) return VK_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return VK_EINVAL;
+    for (uint32_t i = 0; i < nsamples; ++i)
+        if (offsets[i] & 15u) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    constexpr uint32_t kSlab = 64;
+    const uint32_t chunks = (reads + 255u) / 256u;
+    for (uint32_t s0 = 0; s0 < nsamples; s0 += kSlab) {
+        const uint32_t n = nsamples - s0 < kSlab ? nsamples - s0 : kSlab;
+        int rc = synth_shapes(ctx, sample0 + s0, n, reads, readlen, seed);
+        if (rc) return rc;
+        rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_synth_offs), &ctx->synth_offs_cap, kSlab * sizeof(uint64_t));
+        if (rc) return rc;
+        // (pageable source: the copy has read it on return)
+        VK_HIP(ctx, hipMemcpyAsync(ctx->d_synth_offs, offsets + s0, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(vk_synth_shaped_kernel, dim3(n * chunks), dim3(256), 0, ctx->stream, static_cast<uint8_t*>(d_out),
+                           ctx->d_synth_offs, ctx->d_synth, sample0 + s0, reads, readlen, seed);
+        VK_HIP(ctx, hipGetLastError());
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the workspaces are reused by the next slab
+    }
+    return VK_OK;
+}
+
 int vk_remap_host(vk_ctx* ctx, const uint8_t* img_in, uint32_t nimg, uint32_t npix_in, uint32_t npix_out,
                   const uint32_t* src0, const uint32_t* src1, const uint8_t* w0, const uint8_t* w1, int sum_rc,
                   uint8_t* img_out) {
@@ -1008,6 +1074,27 @@ int vk_preprocess_device(vk_ctx* ctx, const uint8_t* d_img, uint32_t nimg, uint3
     hipLaunchKernelGGL(vk_preprocess_kernel, dim3(nimg), dim3(256), lds, ctx->stream, d_img, side, out, d_bounds,
                        d_coef, kmax, mean, stdv, d_out);
     VK_HIP(ctx, hipGetLastError());
+    return VK_OK;
+}
+
+int vk_last_count_general(vk_ctx* ctx, uint64_t* general_pieces, uint64_t* pieces) {
+    if (!ctx || !general_pieces || !pieces) return VK_EINVAL;
+    *general_pieces = 0;
+    *pieces = 0;
+    if (ctx->last_waves == 0) return VK_OK;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> w(ctx->last_waves);
+    VK_HIP(ctx, hipMemcpyAsync(w.data(), ctx->d_wavephase, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t g = 0, active = 0;
+    for (uint32_t v : w) {
+        if (v & 0x80u) continue;
+        ++active;
+        g += v >> 8;
+    }
+    *general_pieces = g;
+    // every wave's range starts one 64-byte block early and ends with a partial piece: about one piece per wave on top
+    *pieces = (ctx->last_bytes + kPiece - 1) / kPiece + active;
     return VK_OK;
 }
 

@@ -42,9 +42,12 @@ def bgzf_members(buf):
         size = (h[16] | (h[17] << 8)) + 1
         if size < 26 or pos + size > n:
             return None
+        text = int.from_bytes(bytes(mv[pos + size - 4:pos + size]), "little")
+        if text > 65536:     # a BGZF block holds at most 64 KiB of text: anything else is not BGZF (or hostile) and
+            return None      # goes the ordinary way, whose text slot is clamped against the file's size on disk
         offs.append(pos)
         sizes.append(size)
-        texts.append(int.from_bytes(bytes(mv[pos + size - 4:pos + size]), "little"))
+        texts.append(text)
         pos += size
     return (np.array(offs, dtype=np.uint64), np.array(sizes, dtype=np.uint64), np.array(texts, dtype=np.uint64))
 
@@ -202,6 +205,13 @@ class ImageEngine:
         n = len(paths)
         is_gz = np.array([g for g, _, _ in info], dtype=bool)
         disk = np.array([d for _, d, _ in info], dtype=np.uint64)
+        unreadable = np.zeros(n, dtype=bool)   # files that exist on the command line but could not be read
+        for i, p in enumerate(paths):
+            if int(disk[i]) == 0:
+                try:
+                    unreadable[i] = os.path.getsize(p) != 0    # (a gzip file under 18 bytes is not one)
+                except OSError:
+                    unreadable[i] = True
         lens = np.array([0 if g else t for g, _, t in info], dtype=np.uint64)      # gzip: known after the inflate
         caps = np.array([t for _, _, t in info], dtype=np.uint64)                  # text slot sizes
         for i in np.flatnonzero(is_gz):
@@ -284,6 +294,7 @@ class ImageEngine:
                     disk[i] = 0
                     lens[i] = 0
                     caps[i] = 0
+                    unreadable[i] = True
                 elif is_gz[i] and nb >= 28 and host[o + 3] & 4:
                     # many-member files (BGZF): the text size is the sum over the members, found by walking
                     # the block headers -- not the last member's size word (0 for BGZF's empty end marker)
@@ -301,7 +312,7 @@ class ImageEngine:
         text_total = pos + 16
         return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
-                "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped}
+                "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped, "unreadable": unreadable}
 
     def _release_mapped(self, mapped, which=None):
         """Unpin and unmap files of a batch (all, or those named) -- on a helper thread: it is a few milliseconds per
@@ -331,10 +342,20 @@ class ImageEngine:
         inflated in HBM into their text slots (vk_inflate_device).  Returns (tensor, offsets, lengths);
         the staging buffer may be refilled once this returns.  A gzip file the GPU rejects (bad header
         or data, truncated, size word or CRC-32 wrong) gets length 0 and a line on stderr."""
+        mapped = staged.get("mapped") or {}
+        try:
+            return self._upload_staged(staged, mapped, timings)
+        finally:
+            if mapped:      # also when a call in there raised: the files' pages must not stay pinned
+                self._release_mapped(mapped)
+
+    def _upload_staged(self, staged, mapped, timings):
         torch = _torch()
         pinned, plain_total, stage_total = staged["pinned"], staged["plain_total"], staged["stage_total"]
         offs, lens, is_gz = staged["offs"], staged["lens"].copy(), staged["is_gz"]
-        mapped = staged.get("mapped") or {}
+        # per file: 0 = its text is in HBM (possibly empty), VK_GZ_* bits of a failed inflate, 0x100 = unreadable
+        fstat = np.where(staged.get("unreadable", np.zeros(len(offs), dtype=bool)), 0x100, 0).astype(np.uint32)
+        self.last_upload_status = fstat
         idx = [i for i in sorted(mapped) if not is_gz[i]]
         if idx:
             # (zeroed: a mapped file brings no padding up to its 16-byte rounded end along)
@@ -413,8 +434,10 @@ class ImageEngine:
                     break
                 oi = gi[over]
                 # (a length beyond the slot is the size the call reported as needed; one within it is what fitted)
+                # -- never a slot that is not larger than the one that just overflowed (a small file's first slot,
+                # 64x its size, is above the ladder's first steps)
                 c2 = np.array([int(got[jj]) if int(got[jj]) > tried[jj] else
-                               int(staged["disk"][gi[jj]]) * grow + (1 << 16) for jj in over], dtype=np.uint64)
+                               max(int(staged["disk"][gi[jj]]) * grow + (1 << 16), 2 * tried[jj]) for jj in over], dtype=np.uint64)
                 for j, jj in enumerate(over):
                     tried[jj] = int(c2[j])
                 o2 = np.zeros(oi.size, dtype=np.uint64)
@@ -438,6 +461,7 @@ class ImageEngine:
             for j, i in enumerate(gi):
                 if st[j]:
                     print(f"gzip inflate failed (status {int(st[j])}):", staged["paths"][i], file=sys.stderr)
+                    fstat[i] = st[j]
                 else:
                     lens[i] = got[j]
             if mapped:
@@ -538,8 +562,23 @@ class ImageEngine:
         return img, hist, status
 
     def synth(self, sample0, nsamples, reads, readlen=150, seed=20250824, dist=0, out=None):
-        """Synthetic FASTQ for samples sample0..sample0+nsamples-1, generated in HBM."""
+        """Synthetic FASTQ for samples sample0..sample0+nsamples-1, generated in HBM (dist 0, 1: records of one
+        size; dist 2: reads shaped like fastp's output, samples of different sizes -- synth.py)."""
         torch = _torch()
+        u64p = C.POINTER(C.c_uint64)
+        if dist == 2:
+            lens = np.zeros(nsamples, dtype=np.uint64)
+            _capi.check(self.ctx, self.L.vk_synth_shaped_lengths(self.ctx, sample0, nsamples, reads, readlen, C.c_uint64(seed),
+                                                                  lens.ctypes.data_as(u64p)), "vk_synth_shaped_lengths")
+            offs = np.zeros(nsamples, dtype=np.uint64)
+            if nsamples > 1:
+                offs[1:] = np.cumsum((lens[:-1] + np.uint64(15)) // np.uint64(16) * np.uint64(16))
+            total = int(offs[-1] + lens[-1]) if nsamples else 0
+            if out is None or out.numel() < (total + 15) // 16 * 16 + 16:
+                out = torch.empty(((total + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=self.device)
+            _capi.check(self.ctx, self.L.vk_synth_shaped_device(self.ctx, self._ptr(out), offs.ctypes.data_as(u64p), sample0,
+                                                                 nsamples, reads, readlen, C.c_uint64(seed)), "vk_synth_shaped_device")
+            return out, offs, lens
         rec = 2 * readlen + 20
         total = rec * reads * nsamples
         if out is None:
@@ -555,6 +594,12 @@ class ImageEngine:
         g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self.L.vk_last_count_launch(self.ctx, C.byref(g), C.byref(b), C.byref(l))
         return {"grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    def last_count_general(self):
+        """(pieces of the last k <= 7 count that took the general path, pieces in all)"""
+        g, n = C.c_uint64(), C.c_uint64()
+        _capi.check(self.ctx, self.L.vk_last_count_general(self.ctx, C.byref(g), C.byref(n)), "vk_last_count_general")
+        return g.value, n.value
 
     # -- host conveniences -------------------------------------------------------
     def count_host(self, data):

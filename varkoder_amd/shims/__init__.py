@@ -66,8 +66,9 @@ def dsk_main(argv=None):
     eng = ImageEngine(k=k, mapping="cgr", device=int(os.environ.get("VARKODER_AMD_DEVICE", "0")))
     try:
         dev, offs, lens = eng.upload_files([opts["-file"]])
-        if os.path.getsize(opts["-file"]) and not int(lens[0]):
-            print(f"dsk (varkoder_amd shim): {opts['-file']} is not a readable FASTQ / gzip file", file=sys.stderr)
+        if int(eng.last_upload_status[0]):   # unreadable, or a gzip file the inflate rejected (an EMPTY text is a valid input)
+            print(f"dsk (varkoder_amd shim): {opts['-file']} is not a readable FASTQ / gzip file "
+                  f"(status {int(eng.last_upload_status[0])})", file=sys.stderr)
             return 1
         h, st = eng.count(dev, offs, lens)
         hist, stw = h.cpu().numpy().view(np.uint32)[0].copy(), int(st.cpu()[0])

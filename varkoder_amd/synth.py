@@ -4,6 +4,12 @@ to vk_synth_kernel in csrc/vkimg.hip (same counter-based splitmix64 keys).
 Record = "@sSSSSS.RRRRRRR\\n" + bases + "\\n+\\n" + "I"*readlen + "\\n" = 2*readlen+20 bytes
 (320 at readlen 150).  dist 0 = uniform ACGT; dist 1 = per-sample GC skew plus 1 read in
 200 carrying a 20-60 base homopolymer run; N injected at ~1e-3 per base.
+
+dist 2 = reads shaped like what step B of the reference hands to step D (fastp --merge --include_unmerged
+--disable_length_filtering, varKoder/commands/image.py:405,426-427,494-495): per read 65 % `readlen` bases,
+20 % merged pairs of readlen+1 .. 2*readlen-10, 10 % trimmed reads of 45 .. readlen-1, 5 % of 0 .. 44 bases
+(empty reads included); header lines of 40 .. 70 bytes; quality characters '!' .. 'I' ('@' and '+' among
+them); bases as dist 0.  Records differ in size: shaped_layout() gives their offsets.
 """
 import numpy as np
 
@@ -52,8 +58,63 @@ def sample_bases(sample, reads, readlen, seed=SEED, dist=0):
     return np.where(isn, np.uint8(ord("N")), out).astype(np.uint8)
 
 
+_FILL = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ:_/=0123456789", dtype=np.uint8)
+
+
+def shaped_layout(sample, reads, readlen=150, seed=SEED):
+    """dist 2: (header line bytes, bases, record offsets [reads + 1]) of every read of a sample."""
+    if not 64 <= readlen <= 1000:
+        raise ValueError("dist 2 needs 64 <= readlen <= 1000")
+    h = _mix(seed, sample, np.arange(reads, dtype=_U), 0, 5)
+    u = h % _U(100)
+    v = (h >> _U(8)) & _U(0xFFFFFF)
+    ln = np.where(u < 65, _U(readlen), np.where(u < 85, _U(readlen + 1) + v % _U(readlen - 10),
+                  np.where(u < 95, _U(45) + v % _U(readlen - 45), v % _U(45)))).astype(np.int64)
+    hl = (40 + ((h >> _U(40)) % _U(31))).astype(np.int64)
+    off = np.zeros(reads + 1, dtype=np.int64)
+    np.cumsum(hl + 2 * ln + 4, out=off[1:])
+    return hl, ln, off
+
+
+def _shaped_fastq(sample, reads, readlen, seed):
+    hl, ln, off = shaped_layout(sample, reads, readlen, seed)
+    total = int(off[-1])
+    o = np.arange(total, dtype=np.int64)
+    r = np.searchsorted(off, o, side="right") - 1          # the read every byte belongs to
+    p = o - off[r]                                            # its place in the record
+    hlr, lnr = hl[r], ln[r]
+    out = np.full(total, ord("\n"), dtype=np.uint8)
+    # header line: "@sSSSSS.RRRRRRR" + ' ' + filler + newline
+    hdr = np.array([f"@s{sample:05d}.{i:07d}".encode() for i in range(reads)], dtype="S15").view(np.uint8).reshape(reads, 15)
+    m = p < 15
+    out[m] = hdr[r[m], p[m]]
+    out[p == 15] = ord(" ")
+    m = (p > 15) & (p < hlr - 1)
+    out[m] = _FILL[(p[m] + r[m]) % 40]
+    out[p == hlr - 1] = ord("\n")     # (a 16-byte header cannot occur: hl >= 40)
+    # bases (dist 0's rule, the position inside the read as the key)
+    q = p - hlr
+    m = (q >= 0) & (q < lnr)
+    i, rr = q[m].astype(_U), r[m].astype(_U)
+    w, j = i >> _U(4), i & _U(15)
+    b = (_mix(seed, sample, rr, w, 1) >> (_U(2) * j)) & _U(3)
+    hn = _mix(seed, sample, rr, w, 2)
+    isn = (((hn >> _U(8)) & _U(63)) == 0) & ((hn & _U(15)) == j)
+    out[m] = np.where(isn, np.uint8(ord("N")), np.frombuffer(b"ACGT", dtype=np.uint8)[b.astype(np.int64)])
+    # "\n+\n", quality, "\n"
+    q = q - lnr
+    out[q == 1] = ord("+")
+    q = q - 3
+    m = (q >= 0) & (q < lnr)
+    i, rr = q[m].astype(_U), r[m].astype(_U)
+    out[m] = (33 + ((_mix(seed, sample, rr, i >> _U(3), 6) >> (_U(8) * (i & _U(7)))) & _U(0xFF)) % _U(41)).astype(np.uint8)
+    return out
+
+
 def sample_fastq(sample, reads, readlen=150, seed=SEED, dist=0):
-    """uint8[reads * (2*readlen+20)] FASTQ text of one sample."""
+    """uint8 FASTQ text of one sample (reads * (2*readlen+20) bytes for dist 0 and 1)."""
+    if dist == 2:
+        return _shaped_fastq(sample, reads, readlen, seed)
     rec = record_bytes(readlen)
     buf = np.empty((reads, rec), dtype=np.uint8)
     hdr = np.array([f"@s{sample:05d}.{r:07d}\n".encode() for r in range(reads)], dtype="S16")

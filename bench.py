@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-config4", action="store_true", help="skip the k=9 side leg (N=1 only)")
     ap.add_argument("--config4-samples", type=int, default=100)
     ap.add_argument("--config4-steps", type=int, default=5)
+    ap.add_argument("--no-realistic", action="store_true", help="skip the fastp-shaped read-length leg (N=1 only)")
+    ap.add_argument("--realistic-pool", type=int, default=256)
+    ap.add_argument("--realistic-steps", type=int, default=3)
     ap.add_argument("--e2e-files", type=int, default=256)
     ap.add_argument("--e2e-reads", type=int, default=560_000, help="reads per file of the end-to-end measurement "
                     "(256 x 560k x 150 bp = 21.5 Gbases: about a second per pass)")
@@ -120,10 +123,17 @@ def cpu_budget():
             "usable_cores": usable}
 
 
-def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
+class VerifyError(RuntimeError):
+    pass
+
+
+def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds, gpu_hist=None, gpu_img=None):
     """The oracle's C restatement ("port") timed on this host's cores on a bounded sample
     of the same workload: whole samples of the device-generated pool, copied back.  Runs on every
-    core this process may use (cpu_budget) and, for the record, on one thread."""
+    core this process may use (cpu_budget) and, for the record, on one thread.
+    The samples it counts are the first entries of the timed batch: their histograms and images as the GPU
+    left them in the last timed step (gpu_hist, gpu_img) must equal the oracle's -- `verified_samples`; a
+    difference raises VerifyError and the bench exits non-zero."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     from varkoder_amd.mapping import pixel_lut, side
@@ -135,6 +145,16 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
     bases_per_sample = args.reads * args.readlen
     budget = cpu_budget()
     cores = args.cpu_threads if args.cpu_threads > 0 else budget["usable_cores"]
+    verified = 0
+    if gpu_hist is not None and gpu_img is not None:
+        with ThreadPoolExecutor(nbuf) as ex:
+            want = list(ex.map(lambda i: (oracle.count_fastq(bufs[i], args.k), oracle.fastq_to_image(bufs[i], args.k, lut, n * n)), range(nbuf)))
+        for i, ((wh, _, st), (wi, _, _)) in enumerate(want):
+            gh = gpu_hist[i].cpu().numpy().view(np.uint32)
+            gi = gpu_img[i].cpu().numpy().ravel()
+            if st != 0 or not np.array_equal(gh, wh) or not np.array_equal(gi, wi):
+                raise VerifyError("batch entry %d: the GPU's histogram / image differs from the oracle's" % i)
+            verified += 1
 
     def one(i):
         img, nwin, st = oracle.fastq_to_image(bufs[i % nbuf], args.k, lut, n * n)
@@ -155,7 +175,8 @@ def cpu_baseline(eng, fastq_dev, offs, lens, args, seconds):
            "kind": "port", "single_thread_value": bases_per_sample / t1 / 1e9, "cpu_model": cpu_model(),
            "speedup_over_one_thread": (nsamp * bases_per_sample / dt) / (bases_per_sample / t1),
            "sample": f"{nsamp} samples of {args.reads} x {args.readlen} bp (FASTQ->counts->image, "
-                     f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)"}
+                     f"oracle/vk_oracle.c, {cores} threads, {dt:.1f} s)",
+           "verified_samples": verified}
     out.update(budget)
     ref = dsk_reference(bufs[0], args, cores)
     if ref:
@@ -291,42 +312,65 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
     nfiles, reads = args.e2e_files_per_rank, args.e2e_reads
     threads = max(1, usable_cores() // world)
     tmp = Path(tempfile.mkdtemp(prefix="vk_e2e_r%d_" % rank))
-    res = None
+
+    def everyone(ok):
+        """Did every rank get here in one piece?  (A collective every rank reaches whatever happened to it: a rank
+        that failed must not leave the others waiting in the next barrier.)"""
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
+    res, err, files = None, None, []
     try:
-        fq, offs, lens = eng.synth((2 << 20) + rank * nfiles, nfiles, reads, args.readlen, dist=args.dist)
-        host = fq.cpu().numpy()
-        del fq
-        torch.cuda.empty_cache()
-        kb = reads * args.readlen // 1000
-        files = [tmp / f"r{rank}s{i:04d}@{kb:08d}K.fq" for i in range(nfiles)]
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda i: host[int(offs[i]):int(offs[i]) + int(lens[i])].tofile(files[i]), range(nfiles)))
-        del host
-        pipeline.fastqs_to_images(files, tmp / "warm", k=args.k, mapping_code=args.mapping, io_threads=threads, engine=eng)
-        shutil.rmtree(tmp / "warm", ignore_errors=True)
+        try:
+            fq, offs, lens = eng.synth((2 << 20) + rank * nfiles, nfiles, reads, args.readlen, dist=args.dist)
+            host = fq.cpu().numpy()
+            del fq
+            torch.cuda.empty_cache()
+            kb = reads * args.readlen // 1000
+            files = [tmp / f"r{rank}s{i:04d}@{kb:08d}K.fq" for i in range(nfiles)]
+            with ThreadPoolExecutor(threads) as ex:
+                list(ex.map(lambda i: host[int(offs[i]):int(offs[i]) + int(lens[i])].tofile(files[i]), range(nfiles)))
+            del host
+            pipeline.fastqs_to_images(files, tmp / "warm", k=args.k, mapping_code=args.mapping, io_threads=threads, engine=eng)
+            shutil.rmtree(tmp / "warm", ignore_errors=True)
+        except Exception as e:  # noqa: BLE001 -- a side measurement: never lose the bench line over it
+            err = repr(e)
+        if not everyone(err is None):
+            return {"error": err or "another rank failed while writing its files"}
         per_pass = []
         for rep in range(max(1, args.e2e_passes)):
             dist.barrier()
-            t0 = time.perf_counter()
-            stats = pipeline.fastqs_to_images(files, tmp / ("img%d" % rep), k=args.k, mapping_code=args.mapping,
-                                              io_threads=threads, engine=eng)
-            dt = time.perf_counter() - t0
-            ok = len(stats) == nfiles and all("failed_step" not in v for v in stats.values())
-            mine = torch.tensor([dt if ok else -1.0], dtype=torch.float64, device=red_dev)
+            dt = -1.0
+            try:
+                t0 = time.perf_counter()
+                stats = pipeline.fastqs_to_images(files, tmp / ("img%d" % rep), k=args.k, mapping_code=args.mapping,
+                                                  io_threads=threads, engine=eng)
+                dt = time.perf_counter() - t0
+                if not (len(stats) == nfiles and all("failed_step" not in v for v in stats.values())):
+                    dt = -1.0
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            mine = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             every = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(every, mine)
             per_pass.append([float(x.item()) for x in every])
+            if min(per_pass[-1]) < 0:      # (every rank sees the same list: all leave together)
+                break
         bases = world * nfiles * reads * args.readlen
-        worst = [max(p) for p in per_pass]
-        mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
+        good = [p for p in per_pass if min(p) > 0]
         from varkoder_amd.engine import plain_route
         res = {"files_per_rank": nfiles, "reads_per_file": reads, "io_threads_per_rank": threads,
-               "plain_text_route": plain_route(threads), "gbases_per_s": bases / worst[mid] / 1e9, "seconds": worst[mid], "passes_s_by_rank": per_pass,
-               "all_files_ok": all(min(p) > 0 for p in per_pass),
+               "plain_text_route": plain_route(threads), "passes_s_by_rank": per_pass,
+               "all_files_ok": len(good) == len(per_pass),
                "note": "plain-text files -> PNGs on every rank at once, page cache warm; aggregate = all ranks' bases / "
                        "slowest rank, median pass"}
-    except Exception as e:  # a side measurement: never lose the bench line over it
-        res = {"error": repr(e)}
+        if good:
+            worst = [max(p) for p in good]
+            mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
+            res.update(gbases_per_s=bases / worst[mid] / 1e9, seconds=worst[mid])
+        if err:
+            res["error"] = err
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res
@@ -360,7 +404,10 @@ def config4(args, device_index):
     status = torch.empty((n,), dtype=torch.int32, device=dev)
     img = torch.empty((n, eng.side, eng.side), dtype=torch.uint8, device=dev)
     buf = None
-    for dist_code in (0, 1):
+    for dist_code in (0, 1, 2):    # uniform; GC-skew + homopolymers; reads of the lengths fastp writes (synth.py)
+        if dist_code == 2:
+            buf = None
+            torch.cuda.empty_cache()
         buf, offs, lens = eng.synth(7000, n, args.reads, args.readlen, dist=dist_code, out=buf)
         eng.count(buf, offs, lens, hist=hist, status=status)      # warm-up: workspaces are allocated here
         eng.images(hist, img=img)
@@ -377,14 +424,19 @@ def config4(args, device_index):
         wall = (time.perf_counter() - t0) / len(ev)
         count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         image_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-        alg = n * (int(lens[0]) + 4 * ncode)
+        alg = int(np.sum(lens)) + n * 4 * ncode
+        bases = n * args.reads * args.readlen
+        if dist_code == 2:
+            bases = int(round(n * args.reads * 152.3))     # mean read length of the mix (synth.py, dist 2); the text decides `frac`
         leg = {"ms_per_step": wall * 1e3, "count_ms": count_ms, "image_ms": image_ms,
-               "gbases_per_s": n * args.reads * args.readlen / wall / 1e9,
+               "gbases_per_s": bases / wall / 1e9, "fastq_bytes": int(np.sum(lens)),
                "bad_status_samples": int((status != 0).sum().item()), "count_launch": eng.last_count_launch(),
                "roofline": {"bound": "hbm", "kernel": "vk_bucket_kernel + vk_bucket_count_kernel + vk_bucket_merge_kernel",
                             "achieved": alg / (count_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (count_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
-                            "traffic": None, "kernel_ms_profiled": None}}
+                            "traffic": None, "kernel_ms_profiled": None,
+                            "traffic_source": "from_profile_file (profiles/k9_latest.json: separate rocprofv3 runs of this configuration, "
+                                              "not measured in this run); count_ms / image_ms / ms_per_step are this run's HIP events"}}
         want = {"k": k, "samples": n, "reads": args.reads, "readlen": args.readlen, "pool": n, "dist": dist_code}
         for entry in (prof or {}).get("legs", []):
             if entry.get("config") == want:
@@ -394,6 +446,59 @@ def config4(args, device_index):
         out["dist%d" % dist_code] = leg
     eng.close()
     del buf, hist, img, status
+    torch.cuda.empty_cache()
+    return out
+
+
+def realistic(args, device_index):
+    """The k <= 7 count on text shaped like what step B of the reference hands to step D (fastp --merge
+    --include_unmerged --disable_length_filtering, commands/image.py:405,426-427,494-495): reads of 0 .. 290 bases
+    under 40 .. 70 byte headers (synth.py dist 2).  A batch of `samples` cycling through a pool of distinct samples;
+    `frac` is against this text's own algorithmic bytes; `general_piece_fraction` = 4 KiB pieces that left the
+    sequence-only fast path (short reads, see vk_count_dense_kernel) / all pieces."""
+    import torch
+    from varkoder_amd.engine import ImageEngine
+    eng = ImageEngine(k=args.k, mapping=args.mapping, device=device_index)
+    dev = torch.device("cuda", device_index)
+    n, pool = args.samples, min(args.realistic_pool, args.samples)
+    ncode = 4 ** args.k
+    buf, poffs, plens = eng.synth(3000, pool, args.reads, args.readlen, dist=2)
+    idx = np.arange(n) % pool
+    offs, lens = poffs[idx].copy(), plens[idx].copy()
+    hist = torch.empty((n, ncode), dtype=torch.int32, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    out = {"workload": "%d samples x %d reads of 0 .. %d bases (65 %% %d, 20 %% merged pairs, 10 %% trimmed, 5 %% under 45; "
+                       "headers of 40 .. 70 bytes), k=%d, %d distinct samples in HBM" % (n, args.reads, 2 * args.readlen - 10, args.readlen, args.k, pool),
+           "fastq_bytes_per_launch": int(np.sum(lens)), "steps": args.realistic_steps}
+    for name, env in (("dense", None), ("classic", "1")):
+        if env:
+            os.environ["VKIMG_K1_CLASSIC"] = env
+            e2 = ImageEngine(k=args.k, mapping=args.mapping, device=device_index)
+        else:
+            e2 = eng
+        try:
+            e2.count(buf, offs, lens, hist=hist, status=status)
+            torch.cuda.synchronize()
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.realistic_steps)]
+            for e in ev:
+                e[0].record()
+                e2.count(buf, offs, lens, hist=hist, status=status)
+                e[1].record()
+            torch.cuda.synchronize()
+            ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+            alg = int(np.sum(lens)) + n * 4 * ncode
+            leg = {"count_ms": ms, "achieved": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "bad_status_samples": int((status != 0).sum().item())}
+            if not env:
+                g, pcs = e2.last_count_general()
+                leg.update(general_pieces=g, pieces=pcs, general_piece_fraction=g / max(1, pcs))
+            out[name] = leg
+        finally:
+            if env:
+                os.environ.pop("VKIMG_K1_CLASSIC", None)
+                e2.close()
+    eng.close()
+    del buf, hist, status
     torch.cuda.empty_cache()
     return out
 
@@ -550,7 +655,7 @@ def main():
     bad = int((status != 0).sum().item())
     e2e_ranks = None
     if world > 1 and not args.no_e2e:   # (every rank takes part: it is a node-level measurement)
-        del hist, img
+        hist = img = None
         torch.cuda.empty_cache()
         e2e_ranks = end_to_end_ranks(eng, args, rank, world, dist, red_dev)
     count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
@@ -607,7 +712,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": count_kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": count_ms},
+                         "avg_launch_ms": count_ms,
+                         "traffic_source": "from_profile_file (profiles/traffic_latest.json: separate rocprofv3 --pmc passes "
+                                           "of this configuration); achieved / avg_launch_ms are this run's HIP events"},
         }
         if e2e_ranks is not None:
             out["end_to_end"] = e2e_ranks
@@ -618,12 +725,24 @@ def main():
                 out["config4"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(eng, fastq, poffs, plens, args, args.cpu_seconds)
+                # (hist / img: as the last timed step left them; batch entry i = pool sample i for i < pool)
+                out["cpu_baseline"] = cpu_baseline(eng, fastq, poffs, plens, args, args.cpu_seconds, hist, img)
+                out["verified_samples"] = out["cpu_baseline"].get("verified_samples", 0)
+            except VerifyError as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+                out["verified_samples"] = 0
+                out["verify_failed"] = str(e)
+                bad = max(bad, 1)
             except Exception as e:  # the baseline is a reported side figure, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
+        hist = img = fastq = None    # make room: the legs below allocate their own batches
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_realistic and args.k <= 7:
+            try:
+                out["realistic"] = realistic(args, local_rank)
+            except Exception as e:  # a side measurement: never lose the bench line over it
+                out["realistic"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e:
-            del hist, img, fastq    # make room: the end-to-end run allocates its own batches
-            torch.cuda.empty_cache()
             try:
                 out["end_to_end"] = end_to_end(eng, args)
             except Exception as e:  # a side measurement: never lose the bench line over it

@@ -197,7 +197,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
 // handed through the 64-granule exchange buffer in file order (start tag on bit 7 of the first byte),
 // rounds of 64, the pending granules counted before a piece takes the general path, context from the
 // previous granule of the stream.  `stats` (optional): [0] pieces on the fast path, [1] pieces in all,
-// [2] rounds, [3] granules counted in rounds.
+// [2] rounds, [3] granules counted in rounds, [4] lanes described explicitly.
 template <int K>
 int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status, uint64_t* stats) {
     const uint32_t ncode = 1u << (2 * K);
@@ -238,8 +238,9 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                     Granule q = {{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}};
                     if (lane < n) q = xb[lane];
                     uint32_t IV, SEQ;
-                    vkl::classify_granule(q.a[0] & ~vkl::kGranuleStartTag, q.a[1], q.a[2], q.a[3],
+                    vkl::classify_granule(q.a[0] & ~(vkl::kGranuleStartTag | vkl::kGranuleAllTag), q.a[1], q.a[2], q.a[3],
                                           (q.a[0] & vkl::kGranuleStartTag) != 0u, C[lane], IV, SEQ);
+                    if (q.a[0] & vkl::kGranuleAllTag) SEQ = 0xFFFFFFFFu;
                     bad[lane] = (IV | ~SEQ) & 0x55555555u;
                 }
                 for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -277,10 +278,19 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
                         const uint32_t lph = (pph + excl) & 3u;
                         excl += c;
-                        if (!vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane])) all_plain = false;
+                        if (!vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane])) {
+                            // described explicitly: everything outside its sequence lines blanked, granules sent whole
+                            uint32_t plo, phi;
+                            vkl::phase1_mask64(mlo, mhi, lph, plo, phi);
+                            vkl::blank_outside(d, plo, phi);
+                            if (vkl::explicit_span(plo, phi, sp[lane], ep[lane]))
+                                for (uint32_t g = sp[lane] >> 4; g <= (ep[lane] >> 4); ++g) d[4 * g] |= vkl::kGranuleAllTag;
+                            memcpy(piece + 64 * lane, d, 64);
+                            if (stats) stats[4]++;
+                        }
                     }
                     total = excl;
-                    fast = all_plain;
+                    (void)all_plain;
                 }
                 if (fast) {
                     if (stats) stats[0]++;

@@ -29,6 +29,14 @@ def test_extension_builds_for_gfx950():
     assert os.path.exists(so)
 
 
+@pytest.mark.gpu
+def test_extension_builds_for_gfx950_on_the_gpu_box():
+    """The same under `-m gpu` (the suite the driver runs): the tree as shipped compiles from clean, to a temporary
+    path, whatever binary travelled with it."""
+    v = build.verify_compiles()
+    assert v["bytes"] > 100000 and v["seconds"] > 0
+
+
 def test_library_exports_every_declared_symbol():
     if not os.path.exists(_capi.LIB_PATH):
         build.build_hip()

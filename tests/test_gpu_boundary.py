@@ -236,7 +236,7 @@ def test_bench_script_runs_end_to_end(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
                           "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5", "--e2e-files", "6",
-                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2"],
+                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2", "--realistic-pool", "8", "--realistic-steps", "2"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -258,10 +258,18 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert e["fq_gz"]["file_bytes"] < e["plain_text"]["file_bytes"] and e["gz_pngs_identical_to_plain"]
     c4 = d["config4"]                                   # BASELINE configs[3] as a side leg: k=9 cgr, both distributions
     assert c4["k"] == 9 and c4["samples"] == 6
-    for leg in ("dist0", "dist1"):
+    for leg in ("dist0", "dist1", "dist2"):
         assert c4[leg]["bad_status_samples"] == 0 and c4[leg]["count_ms"] > 0
         rr = c4[leg]["roofline"]
         assert rr["bound"] == "hbm" and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-9 and rr["traffic"] is None
+        assert rr["traffic_source"].startswith("from_profile_file")
+    assert c4["dist2"]["fastq_bytes"] != c4["dist0"]["fastq_bytes"]
+    # the line checks itself: the first batch entries' histograms and images against the oracle's
+    assert d["verified_samples"] == 4 and d["cpu_baseline"]["verified_samples"] == 4 and "verify_failed" not in d
+    rl = d["realistic"]                                 # reads of the lengths fastp writes (synth.py dist 2)
+    for leg in ("dense", "classic"):
+        assert rl[leg]["bad_status_samples"] == 0 and rl[leg]["count_ms"] > 0
+    assert 0 < rl["dense"]["general_piece_fraction"] <= 1 and rl["dense"]["pieces"] > 0
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():

@@ -284,6 +284,49 @@ def test_spill_path_with_a_full_arena_counts_directly(k, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("k", (8, 9))
+def test_spill_replay_pair_counters_wrap_and_the_wide_replay_takes_over(engines, k, monkeypatch):
+    """Pass B of k = 8, 9 counts PAIRS in u16 counters; 65536 equal pairs in one bucket stream wrap one, the job's
+    counters then do not add up to its entries and the job is replayed into u32 window counters
+    (vk_bucket_count_wide_kernel).  A repeat of period 10 (beyond what the low-complexity shortcuts of pass A take
+    out: period <= 8) in 60,000 reads does that to the buckets its pairs fall into, the random reads beside it keep
+    the other buckets on the u16 path -- one histogram, from both tables.  Also: every job forced through the wide
+    replay (VKIMG_SPILL_FORCE_WIDE) gives the same histogram as the shipped path."""
+    from fastq_cases import rec
+    from varkoder_amd.engine import ImageEngine
+    rng = np.random.default_rng(7 + k)
+    unit = "ACGTTGCATC"
+    reads = []
+    for i in range(80000):
+        if i % 4 != 3:
+            ph = int(rng.integers(0, 10))
+            seq = (unit * 17)[ph:ph + 150]
+        else:
+            seq = "".join(rng.choice(list("ACGT"), size=150))
+        reads.append(rec(f"r{i}", seq))
+    fq = b"".join(reads)
+    want, nwin, st = oracle.count_fastq(fq, k)
+    assert st == 0 and int(want.max()) > 3 * 65536
+    eng = engines(k)
+    dev, offs, lens = eng.upload([fq])
+    for parts in (1, 5):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        assert np.array_equal(hist.cpu().numpy().view(np.uint32)[0], want), parts
+    monkeypatch.setenv("VKIMG_SPILL_FORCE_WIDE", "1")
+    e2 = ImageEngine(k=k, mapping="cgr", device=0)
+    try:
+        samples = [synth.sample_fastq(70 + i, 5000, 150, dist=i) for i in range(3)]
+        d2, o2, l2 = e2.upload(samples + [fq])
+        hist, status = e2.count(d2, o2, l2)
+        got = hist.cpu().numpy().view(np.uint32)
+        for i, smp in enumerate(samples):
+            assert np.array_equal(got[i], oracle.count_fastq(smp, k)[0]), i
+        assert np.array_equal(got[3], want)
+    finally:
+        e2.close()
+
+
 @pytest.mark.parametrize("k", KS)
 def test_count_fuzz_batches(engines, k):
     """Hundreds of random adversarial (well-formed) FASTQ samples per launch, random workgroup

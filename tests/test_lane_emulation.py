@@ -57,7 +57,7 @@ def emul():
         pad[:buf.size] = buf
         hist = np.zeros(4 ** k, dtype=np.uint32)
         st = C.c_uint32(0)
-        stats = (C.c_uint64 * 4)()
+        stats = (C.c_uint64 * 5)()
         L.emul_count_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.emul_count_dense(pad.ctypes.data, buf.size, k, parts, hist.ctypes.data, C.byref(st), stats) == 0
         return hist, st.value, tuple(stats)
@@ -148,14 +148,35 @@ def test_dense_stage_equals_oracle_on_synthetic_and_takes_the_fast_path(emul, di
     fq = synth.sample_fastq(21, 40000, 150, dist=dist)   # 12.8 MB: ~190 pieces per wave at parts = 1
     for k, parts in ((5, 1), (7, 1), (7, 3), (6, 7)):
         want = oracle.count_fastq(fq, k)[0]
-        got, status, (fast, pieces, rounds, granules) = emul.dense(fq, k, parts)
-        assert status == 0
+        got, status, (fast, pieces, rounds, granules, explicit) = emul.dense(fq, k, parts)
+        assert status == 0 and explicit == 0
         assert np.array_equal(got, want), (k, parts)
         # every piece but the first and last of a range goes through the line pass, and the rounds are full
         assert fast >= pieces - 2 * 16 * parts, (fast, pieces)
         assert granules > 60 * rounds
         # sequence bytes are 151 of 320: the heavy stage sees little more than half of the granules
         assert granules * 16 < 0.56 * len(fq), (granules * 16, len(fq))
+
+
+def test_dense_stage_keeps_fastp_shaped_reads_on_the_fast_path(emul):
+    """Reads of every length from 0 to 290 under 40 .. 70 byte headers (synth.py dist 2, what fastp writes for the
+    reference's step D): a lane that begins in a quality line and holds its end and a whole header is ordinary
+    (seq_span), lanes with four and more newlines are described explicitly -- no piece falls back to the general
+    path but the first and last of a range."""
+    fq = synth.sample_fastq(33, 30000, 150, dist=2)
+    for k, parts in ((7, 1), (5, 2), (6, 5)):
+        want = oracle.count_fastq(fq, k)[0]
+        got, status, (fast, pieces, rounds, granules, explicit) = emul.dense(fq, k, parts)
+        assert status == 0
+        assert np.array_equal(got, want), (k, parts)
+        assert fast >= pieces - 2 * 16 * parts, (fast, pieces)
+        assert 0 < explicit < 0.02 * 64 * pieces, (explicit, pieces)
+    # the same text with every header cut to "@r": records of a few bytes more than their two long lines
+    short = b"".join(b"@r\n" + l if i % 4 == 0 else l for i, l in enumerate(x[x.index(b"\n") + 1:] if i % 4 == 0 else x
+                     for i, x in enumerate(fq.tobytes().splitlines(keepends=True))))
+    want = oracle.count_fastq(short, 7)[0]
+    got, status, stats = emul.dense(short, 7, 1)
+    assert status == 0 and np.array_equal(got, want), stats
 
 
 def test_dense_stage_fuzz(emul):

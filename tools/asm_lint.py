@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Hazard lint for the hand-written asm statements of the extension (gfx950).
+
+hipcc's hazard recogniser pads the instruction pairs it schedules itself; it does not look inside an
+inline-asm statement, and after one it only adds its fixed boundary pad.  A pair whose producer OR
+consumer sits inside `;;#ASMSTART` .. `;;#ASMEND` therefore needs its wait states written by hand
+(round 3's incident: a hand-fused `v_lshl_or_b32` read `v_dot4_u32_u8` results three wait states too
+early -- stale masks, caught only because a later test refused the garbage).  This script walks the
+device assembly (`hipcc -S --cuda-device-only`) and reports every such pair that has fewer wait states
+between producer and consumer than the gfx90a/gfx940 rules ask for:
+
+  DOT      v_dot*  writes a VGPR  ->  another VALU reads it (3) or writes it (4)
+  TRANS    v_exp/log/rcp/rsq/sqrt/sin/cos writes a VGPR  ->  a non-trans VALU reads it (1)
+  SGPR-VM  a VALU writes an SGPR (v_cmp*_e64, carry-out, v_readlane, v_readfirstlane)  ->  a buffer_/global_/
+           flat_/scratch_ instruction reads it (5)
+  SGPR-LN  a VALU writes an SGPR / VCC  ->  v_readlane / v_writelane takes it as the lane select (4)
+  EXEC-DPP a VALU writes EXEC (v_cmpx)  ->  a DPP instruction (5)
+  VGPR-DPP a VALU writes a VGPR  ->  a DPP instruction reads it (2)
+  VGPR-RL  a VALU writes a VGPR  ->  v_readlane / v_readfirstlane reads it (1)
+  M0-LDS   an SALU writes M0  ->  an LDS-DMA / add-TID / GDS instruction (1)
+  VCC-FMAS a VALU writes VCC  ->  v_div_fmas (4)
+
+Wait states: every instruction between the two counts one, `s_nop N` counts N + 1.  Pairs whose two
+ends are both compiler code are the compiler's business and are not reported.  Branch targets reset
+the window (a label: the straight-line distance no longer holds).
+
+usage: tools/asm_lint.py [file.s]      (no argument: compiles varkoder_amd/csrc/vkimg.hip first)
+exit status 1 when something is found.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)(_|$)")
+VMEM = re.compile(r"^(buffer_|global_|flat_|scratch_|tbuffer_)")
+DPP = re.compile(r"\b(quad_perm:|row_shl:|row_shr:|row_ror:|wave_shl:|wave_shr:|wave_rol:|wave_ror:|row_mirror|row_half_mirror|row_bcast:|row_newbcast:)")
+REG = re.compile(r"\b([vsa])(\d+)\b|\b([vsa])\[(\d+):(\d+)\]|\b(vcc|exec|m0)(_lo|_hi)?\b")
+
+
+def regs(text):
+    """set of register names in an operand string: v3, s[4:5] -> {s4, s5}, vcc, exec, m0"""
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.add(m.group(1) + m.group(2))
+        elif m.group(3):
+            for i in range(int(m.group(4)), int(m.group(5)) + 1):
+                out.add(m.group(3) + str(i))
+        else:
+            out.add(m.group(6))
+    return out
+
+
+class Ins:
+    __slots__ = ("op", "defs", "uses", "text", "line", "in_asm", "nops", "is_valu", "is_dpp", "lanesel")
+
+
+def parse(op, rest, text):
+    ins = Ins()
+    ins.op, ins.text = op, text
+    ins.nops = 0
+    ins.lanesel = set()
+    ops = [o.strip() for o in rest.split(",")] if rest.strip() else []
+    # modifiers ride on the last operand ("v3 row_shr:1 row_mask:0xf"): regs() skips what is not a register
+    ins.is_valu = op.startswith("v_") and not op.startswith("v_nop")
+    ins.is_dpp = bool(DPP.search(text))
+    ndst = 1
+    if op == "s_nop":
+        ins.nops = int(ops[0], 0) + 1 if ops else 1
+        ins.defs, ins.uses = set(), set()
+        return ins
+    if re.match(r"^v_(add|sub|subrev)c?_co_|^v_(addc|subb|subbrev)_co_|^v_div_scale|^v_mad_(u|i)64_", op):
+        ndst = 2 if not op.endswith("_e32") and not op.endswith("_dpp") and not op.endswith("_sdwa") else 1
+    if op.startswith(("s_cmp", "s_cbranch", "s_waitcnt", "s_barrier", "s_endpgm", "s_sleep", "s_setprio", "s_branch", "s_bitcmp")) or \
+            op.startswith(("ds_write", "ds_add_u", "ds_or_b", "ds_and_b", "ds_max_u", "ds_min_u")) and "rtn" not in op or \
+            re.match(r"^(buffer|global|flat|scratch)_(store|atomic)", op) and "glc" not in text and " sc0" not in text:
+        ndst = 0
+    if op.startswith("v_cmpx"):
+        ndst = 0
+    ins.defs = set()
+    for o in ops[:ndst]:
+        ins.defs |= regs(o)
+    ins.uses = set()
+    for o in ops[ndst:]:
+        ins.uses |= regs(o)
+    if op.startswith("v_cmp") and op.endswith("_e32"):
+        ins.defs = {"vcc"}
+        ins.uses = set()
+        for o in ops:
+            ins.uses |= regs(o)
+        ins.uses.discard("vcc")
+    if op.startswith("v_cmpx"):
+        ins.defs = {"exec"}
+    if op.endswith("_e32") and re.match(r"^v_(add|sub|subrev)_co_|^v_(addc|subb|subbrev)_co_", op):
+        ins.defs |= {"vcc"}
+    if op.startswith(("v_readlane", "v_writelane")) and len(ops) >= 3:
+        ins.lanesel = regs(ops[2])
+    if op.startswith("v_div_fmas"):
+        ins.uses |= {"vcc"}
+    return ins
+
+
+def instructions(lines):
+    """yield (function name, [Ins]) for every function of the assembly"""
+    fn, cur, in_asm = None, [], False
+    for n, raw in enumerate(lines, 1):
+        line = raw.split(";;#")[0] if ";;#ASM" not in raw else raw
+        s = line.strip()
+        if ";;#ASMSTART" in s:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in s:
+            in_asm = False
+            continue
+        s = s.split(";")[0].strip() if not s.startswith(";") else ""
+        if not s:
+            continue
+        m = re.match(r"^([A-Za-z_.$][\w.$]*):", s)
+        if m:
+            name = m.group(1)
+            if not name.startswith((".L", "L")) and not re.match(r"^\d", name):
+                if fn is not None:
+                    yield fn, cur
+                fn, cur = name, []
+            else:
+                cur.append(None)      # a label: the window ends here
+            continue
+        if re.match(r"^\d+:", s):      # local label inside an asm statement
+            cur.append(None)
+            continue
+        if s.startswith("."):
+            continue
+        parts = s.split(None, 1)
+        ins = parse(parts[0], parts[1] if len(parts) > 1 else "", s)
+        ins.line, ins.in_asm = n, in_asm
+        cur.append(ins)
+    if fn is not None:
+        yield fn, cur
+
+
+def lint(lines):
+    found = []
+    for fn, seq in instructions(lines):
+        for i, c in enumerate(seq):
+            if c is None or c.nops:
+                continue
+            waited = 0
+            j = i - 1
+            while j >= 0 and waited < 5:
+                p = seq[j]
+                if p is None:
+                    break
+                if p.nops:
+                    waited += p.nops
+                    j -= 1
+                    continue
+                if p.in_asm or c.in_asm:
+                    for rule, need in check(p, c):
+                        if waited < need:
+                            found.append((fn, rule, need, waited, p, c))
+                waited += 1
+                j -= 1
+    return found
+
+
+def check(p, c):
+    """hazard rules between producer p and a later consumer c: (name, wait states needed)"""
+    out = []
+    vdefs = {r for r in p.defs if r[0] == "v" and r != "vcc"}
+    sdefs = {r for r in p.defs if r[0] == "s" or r == "vcc"}
+    if p.op.startswith("v_dot") and c.is_valu and not (c.op == p.op):
+        if vdefs & c.uses:
+            out.append(("DOT write -> VALU read", 3))
+        if vdefs & c.defs:
+            out.append(("DOT write -> VALU write", 4))
+    if TRANS.match(p.op) and c.is_valu and not TRANS.match(c.op) and vdefs & c.uses:
+        out.append(("TRANS write -> VALU read", 1))
+    if p.is_valu and sdefs:
+        if VMEM.match(c.op) and sdefs & c.uses:
+            out.append(("VALU writes SGPR -> VMEM reads it", 5))
+        if c.lanesel & sdefs:
+            out.append(("VALU writes SGPR -> lane select of v_readlane/v_writelane", 4))
+        if c.op.startswith("v_div_fmas") and "vcc" in sdefs:
+            out.append(("VALU writes VCC -> v_div_fmas", 4))
+    if p.is_valu and "exec" in p.defs and c.is_dpp:
+        out.append(("VALU writes EXEC -> DPP", 5))
+    if p.is_valu and c.is_dpp and vdefs & c.uses:
+        out.append(("VALU writes VGPR -> DPP reads it", 2))
+    if p.is_valu and c.op.startswith(("v_readlane", "v_readfirstlane")) and vdefs & c.uses:
+        out.append(("VALU writes VGPR -> v_readlane/v_readfirstlane reads it", 1))
+    if p.op.startswith("s_") and "m0" in p.defs and (c.op.startswith(("ds_gws", "ds_add_tid", "ds_read_addtid", "ds_write_addtid", "s_sendmsg")) or
+                                                      (VMEM.match(c.op) and " lds" in c.text)):
+        out.append(("SALU writes M0 -> LDS-DMA / add-TID / GDS", 1))
+    return out
+
+
+def device_asm():
+    out = os.path.join(tempfile.mkdtemp(prefix="vk_lint_"), "vkimg.s")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S",
+           "--cuda-device-only", os.path.join(ROOT, "varkoder_amd", "csrc", "vkimg.hip"), "-o", out]
+    subprocess.run(cmd, check=True, capture_output=True, cwd="/tmp")
+    return out
+
+
+def main(argv):
+    path = argv[1] if len(argv) > 1 else device_asm()
+    with open(path) as f:
+        lines = f.read().splitlines()
+    found = lint(lines)
+    nasm = sum(1 for l in lines if ";;#ASMSTART" in l)
+    for fn, rule, need, waited, p, c in found:
+        print(f"{fn}: {rule}: {need} wait states needed, {waited} present")
+        print(f"    line {p.line}{' (asm)' if p.in_asm else ''}: {p.text}")
+        print(f"    line {c.line}{' (asm)' if c.in_asm else ''}: {c.text}")
+    print(f"asm_lint: {nasm} asm statements, {len(found)} findings in {path}")
+    return 1 if found else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

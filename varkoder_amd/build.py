@@ -29,14 +29,34 @@ def needs_build():
 LAST = {}  # what the last build_hip() call did: {"action": "compiled" | "reused", "so": path, "so_mtime": ..., "seconds": ...}
 
 
-def build_hip(force=False, verbose=False):
+def compile_cmd(out):
+    return [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-I", INC, SRC, "-o", out]
+
+
+def verify_compiles():
+    """Compile the tree as it stands to a temporary file (the library in place is left alone): seconds taken and
+    the size of what came out.  Proof that the sources build, for a run that would otherwise reuse the binary."""
+    import tempfile
+    import time
+    with tempfile.TemporaryDirectory(prefix="vkbuild_") as tmp:
+        out = os.path.join(tmp, "libvkimg_hip.so")
+        t0 = time.time()
+        subprocess.check_call(compile_cmd(out))
+        return {"seconds": time.time() - t0, "bytes": os.path.getsize(out)}
+
+
+def build_hip(force=False, verbose=False, verify=False):
+    """The library, compiled when it is missing or older than a source (or with force).  verify: when the
+    binary in place is current, compile the tree to a temporary path anyway and record that it built."""
     import time
     if not force and not needs_build():
         LAST.update(action="reused", so=OUT, so_mtime=os.path.getmtime(OUT), seconds=0.0)
+        if verify:
+            v = verify_compiles()
+            LAST.update(action="reused+verified", seconds=v["seconds"], verified_bytes=v["bytes"])
         return OUT
     t0 = time.time()
-    cmd = [hipcc_path(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-I", INC, SRC, "-o", OUT]
+    cmd = compile_cmd(OUT)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             return;
 #endif
             uint32_t C, IV, SEQ;
-            vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
+            vkl::classify_granule(q.x & ~(vkl::kGranuleStartTag | vkl::kGranuleAllTag), q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
+            // (a granule of an explicitly described lane: everything in it that is not a newline is sequence)
+            SEQ |= static_cast<uint32_t>(static_cast<int32_t>(q.x << 16) >> 31);
             const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
             const uint32_t badh = wave_prev_lane(bad, ctx_bad);
             const uint32_t ch = wave_prev_lane(C, ctx_c);
@@ -1089,7 +1091,31 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 const uint32_t incl = wave_inclusive_sum(c);
                 total = lane_bcast(incl, 63);
                 const uint32_t lph = (pph + incl - c) & 3u;
-                fast = !__any(!vkl::seq_span(mlo, mhi, c, lph, s, e));
+                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e);
+                if (__any(!plain)) {
+                    // Lanes one tagged stretch of granules cannot describe (four or more newlines in 64 bytes, a read under
+                    // 15 bases inside one granule): their line-phase-1 positions found newline by newline, every other byte
+                    // of the lane turned into a newline IN THE PIECE'S REGISTERS, and the granules from the first to the
+                    // last one with such a position sent with kGranuleAllTag.  Rare (reads under ~20-45 bases), exact for
+                    // any text; the lanes beside them stay on the fast path.
+                    if (!plain) {
+                        uint32_t plo, phi, dd[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) dd[i] = d[i];
+                        vkl::phase1_mask64(mlo, mhi, lph, plo, phi);
+                        vkl::blank_outside(dd, plo, phi);
+                        if (vkl::explicit_span(plo, phi, s, e)) {
+                            const uint32_t g0 = s >> 4, g1 = e >> 4;
+#pragma unroll
+                            for (uint32_t g = 0; g < 4; ++g)
+                                if (g >= g0 && g <= g1) dd[4 * g] |= vkl::kGranuleAllTag;
+                        }
+                        r0 = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+                        r1 = make_uint4(dd[4], dd[5], dd[6], dd[7]);
+                        r2 = make_uint4(dd[8], dd[9], dd[10], dd[11]);
+                        r3 = make_uint4(dd[12], dd[13], dd[14], dd[15]);
+                    }
+                }
             }
             if (!fast) {
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
@@ -1223,7 +1249,9 @@ struct BucketParams {
     uint32_t* bucket_hist;  // [nsamples][16][2 * 4^K / 16] pass B's counters, merged into the histogram by pass C
     uint32_t* bsize;     // [nsamples][16] blocks of each bucket stream in the arena (added up as runs are closed)
     uint32_t* order;     // [nsamples * 16] pass B's (sample, bucket) jobs, the large ones first
+    uint32_t* wide;      // [nsamples * 16] != 0: the job's u16 pair counters overflowed, bucket_hist holds u32 window counters instead
     uint32_t runs_cap;
+    uint32_t force_wide; // tests: every job through the u32 replay
 };
 
 // LDS of the bucket kernel, one array with fixed offsets (the hand-written queue appends address it
@@ -1646,7 +1674,124 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
     for (uint32_t j = tid; j < njobs; j += 1024) bp.order[atomicAdd(&first[cls(bp.bsize[j])], 1u)] = j;
 }
 
-// Pass B: one workgroup per (sample, bucket) replays the runs of its bucket into a 2 x 4^K/16-bin
+// Pass B, the shipped replay (vk_bucket_count_kernel): ONE LDS add per PAIR.  A pair entry e (LB + 2 bits: the K - 2
+// bases before the bucket's two, and the base after them) names both of its windows, so the entry itself is counted:
+// 4^(K+1) / 16 pair counters per bucket, u16 each, two to a word -- word = the low LB + 1 bits of e, half = its top
+// bit -- which is the 128 KiB (K = 9) the two u32 window tables took.  Pass C sums, per k-mer code, the four pair
+// counters that hold it as their first window and the four that hold it as their second.  Half the LDS atomics of
+// counting windows (the replay is bound by their bank conflicts).
+// A u16 counter wraps after 65535 equal pairs of one bucket stream (poly-A tails of a whole sample do that): the
+// wrap carries into the neighbouring counter or out of the word, either way the sum over all counters no longer
+// equals the number of entries replayed (each wrap loses 65535 or 65536, and there are fewer than 2^30 entries), so
+// the job compares the two, and a job that does not add up is flagged (bp.wide) and replayed by
+// vk_bucket_count_wide_kernel into u32 WINDOW counters (the replay of rounds 1-3, two adds per pair); pass C reads
+// whichever table the flag names.  Exact either way.
+template <int K>
+__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp) {
+    constexpr uint32_t LB = 2 * K - 4;
+    constexpr uint32_t WORDS = 2u << LB;  // u32 words = pair counters / 2
+    constexpr uint32_t kList = 4096;      // runs listed per round (a uniform sample has ~2400 per bucket)
+    __shared__ uint32_t hist[WORDS];
+    __shared__ uint32_t list[kList];
+    __shared__ uint32_t nlist, sum_all, sum_tallied;
+    const uint32_t job = bp.order[blockIdx.x];  // large streams first (vk_bucket_order_kernel)
+    const uint32_t s = job / kQueues, q = job % kQueues;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < WORDS; i += kCountThreads) hist[i] = 0u;
+    if (tid == 0) { sum_all = 0u; sum_tallied = 0u; }
+    uint32_t nruns = bp.cursors[s];
+    if (nruns > bp.runs_cap) nruns = bp.runs_cap;
+    const uint32_t* hdrs = bp.hdrs + static_cast<uint64_t>(s) * bp.runs_cap;
+    const uint8_t* arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
+    // entry e (u16; garbage above bit LB + 1 for K = 8): byte address of its word (e << 2) & M, addend 1 or 0x10000 by bit LB + 1
+    constexpr uint32_t M = ((1u << (LB + 1)) - 1u) << 2;
+    uint8_t* const h0 = reinterpret_cast<uint8_t*>(hist);
+    auto tally2 = [&](uint32_t w) __attribute__((always_inline)) {  // two entries: the halves of a dword
+        const uint32_t t0 = (w >> (LB + 1)) & 1u, t1 = (w >> (LB + 17)) & 1u;
+        atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w << 2) & M)), __umul24(t0, 0xFFFFu) + 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w >> 14) & M)), __umul24(t1, 0xFFFFu) + 1u);
+    };
+    const uint32_t g = tid & 255u;   // 256 threads per run: the 16-byte granule this thread reads (four per block)
+    const uint32_t grp = tid >> 8;   // four runs at a time
+    auto fetch = [&](uint32_t i, uint32_t n, uint4& v) __attribute__((always_inline)) -> bool {
+        const uint32_t item = i < n ? list[i] : 0u;
+        const bool have = i < n && (g >> 2) < (item >> 24);
+        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
+        return have;
+    };
+    uint32_t tallied = 0;            // entries this thread replayed
+    auto tally4 = [&](const uint4& v) __attribute__((always_inline)) {
+        tally2(v.x);
+        tally2(v.y);
+        tally2(v.z);
+        tally2(v.w);
+        tallied += 8u;
+    };
+    uint32_t r0 = 0;
+    while (r0 < nruns) {
+        if (tid == 0) nlist = 0u;
+        __syncthreads();
+        uint32_t listed = 0;
+        for (; r0 < nruns; r0 += kCountThreads) {
+            if (listed + kCountThreads > kList) break;
+            const uint32_t r = r0 + tid;
+            const uint32_t h = r < nruns ? hdrs[r] : 0u;
+            const bool mine = (h >> 31) != 0u && (h & 0xFFu) == q;
+            const unsigned long long bal = __ballot(mine);
+            uint32_t base = 0;
+            if ((tid & 63u) == 0u && bal != 0ull) base = atomicAdd(&nlist, static_cast<uint32_t>(__popcll(bal)));
+            base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+            if (mine) list[base + __popcll(bal & ((1ull << (tid & 63u)) - 1ull))] = r | ((h >> 8) & 0xFFu) << 24;
+            __syncthreads();
+            listed = nlist;
+            __syncthreads();
+        }
+        const uint32_t n = listed;
+        uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+        bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
+        uint32_t i = grp;
+        ha0 = fetch(i, n, a0); ha1 = fetch(i + 4, n, a1); ha2 = fetch(i + 8, n, a2); ha3 = fetch(i + 12, n, a3);
+        while (i < n) {
+            hb0 = fetch(i + 16, n, b0); hb1 = fetch(i + 20, n, b1); hb2 = fetch(i + 24, n, b2); hb3 = fetch(i + 28, n, b3);
+            if (ha0) tally4(a0);
+            if (ha1) tally4(a1);
+            if (ha2) tally4(a2);
+            if (ha3) tally4(a3);
+            i += 16;
+            if (i >= n) break;
+            ha0 = fetch(i + 16, n, a0); ha1 = fetch(i + 20, n, a1); ha2 = fetch(i + 24, n, a2); ha3 = fetch(i + 28, n, a3);
+            if (hb0) tally4(b0);
+            if (hb1) tally4(b1);
+            if (hb2) tally4(b2);
+            if (hb3) tally4(b3);
+            i += 16;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    uint32_t* out = bp.bucket_hist + (static_cast<uint64_t>(s) * kQueues + q) * WORDS;
+    uint32_t total = 0;
+    for (uint32_t i = tid; i < WORDS; i += kCountThreads) {
+        const uint32_t w = hist[i];
+        out[i] = w;
+        total += (w & 0xFFFFu) + (w >> 16);
+    }
+    // do the counters add up to the entries replayed?  (wave sums first: two LDS atomics per wavefront)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        total += __shfl_xor(total, d);
+        tallied += __shfl_xor(tallied, d);
+    }
+    if ((tid & 63u) == 0u) {
+        atomicAdd(&sum_all, total);
+        atomicAdd(&sum_tallied, tallied);
+    }
+    __syncthreads();
+    if (tid == 0) bp.wide[job] = (sum_all != sum_tallied || bp.force_wide != 0u) ? 1u : 0u;
+}
+
+// The u32 replay of a job whose pair counters wrapped (see above; rounds 1-3 ran every job through it):
+// one workgroup per (sample, bucket) replays the runs of its bucket into a 2 x 4^K/16-bin
 // LDS histogram and stores it, as it stands, to bucket_hist (plain coalesced stores).
 // Pass C (vk_bucket_merge_kernel): one thread per k-mer code adds the two counters that can name it
 // -- the code seen as the first and as the second window of a pair -- to the histogram, which already
@@ -1654,7 +1799,7 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
 // lane to its own cache line: the bucket number is the END of the first window, the least
 // significant digits of its code; that flush alone took as long as the replay.)
 template <int K>
-__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketParams bp) {
+__global__ __launch_bounds__(kCountThreads) void vk_bucket_count_wide_kernel(BucketParams bp) {
     constexpr uint32_t LB = 2 * K - 4;
     constexpr uint32_t BINS = 2u << LB;  // type bit | index
     constexpr uint32_t kList = 4096;     // runs listed per round (a uniform sample has ~2400 per bucket)
@@ -1662,6 +1807,7 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     __shared__ uint32_t list[kList];
     __shared__ uint32_t nlist;
     const uint32_t job = bp.order[blockIdx.x];  // large streams first (vk_bucket_order_kernel)
+    if (bp.wide[job] == 0u) return;             // the u16 pair counters of vk_bucket_count_kernel held
     const uint32_t s = job / kQueues, q = job % kQueues;
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < BINS; i += kCountThreads) hist[i] = 0u;
@@ -1752,13 +1898,31 @@ __global__ __launch_bounds__(256) void vk_bucket_merge_kernel(BucketParams bp, u
     constexpr uint32_t BINS = 2u << LB;
     const uint32_t s = blockIdx.x / (NCODE / 256), code = (blockIdx.x % (NCODE / 256)) * 256 + threadIdx.x;
     const uint32_t raw = pair_reverse(code, K);  // first base least significant, as the pair entries are built
-    // as the FIRST window of a pair: bucket = its last two bases, counted under its first K - 2 bases
+    // as the FIRST window of a pair: bucket = its last two bases, the entry's low LB bits = its first K - 2 bases
+    // (the base after the pair's bucket bases is any of four)
     const uint32_t q0 = raw >> LB, i0 = raw & ((1u << LB) - 1u);
-    // as the SECOND window: bucket = bases K-3, K-2; counted under (first K - 3 bases | last base << (LB - 2))
+    // as the SECOND window: bucket = bases K-3, K-2; the entry's low LB bits = (any base | its first K - 3 bases),
+    // the entry's top two bits its last base
     const uint32_t q1 = (raw >> (LB - 2)) & 15u;
-    const uint32_t i1 = (raw & ((1u << (LB - 2)) - 1u)) | ((raw >> (2 * K - 2)) << (LB - 2));
+    const uint32_t head = raw & ((1u << (LB - 2)) - 1u), lastb = raw >> (2 * K - 2);
     const uint32_t* bh = bp.bucket_hist + static_cast<uint64_t>(s) * kQueues * BINS;
-    const uint32_t add = bh[q0 * BINS + i0] + bh[q1 * BINS + (1u << LB) + i1];
+    const uint32_t* wide = bp.wide + s * kQueues;
+    uint32_t add;
+    auto halves = [](uint32_t w) { return (w & 0xFFFFu) + (w >> 16); };
+    if (wide[q0] != 0u) {
+        add = bh[q0 * BINS + i0];                                   // u32 window counters: [type][index]
+    } else {
+        // pair counters: word = low LB + 1 bits of the entry, half = its top bit; last base 0..3 = two words, both halves
+        add = halves(bh[q0 * BINS + i0]) + halves(bh[q0 * BINS + i0 + (1u << LB)]);
+    }
+    if (wide[q1] != 0u) {
+        add += bh[q1 * BINS + (1u << LB) + (head | (lastb << (LB - 2)))];
+    } else {
+        // the four entries (any first base) are neighbours: one 16-byte load, the half by the last base's upper bit
+        const uint4 v = *reinterpret_cast<const uint4*>(bh + q1 * BINS + ((head << 2) | ((lastb & 1u) << LB)));
+        const uint32_t sh = (lastb >> 1) * 16u;
+        add += ((v.x >> sh) & 0xFFFFu) + ((v.y >> sh) & 0xFFFFu) + ((v.z >> sh) & 0xFFFFu) + ((v.w >> sh) & 0xFFFFu);
+    }
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
     out[code] += add;
 }

@@ -96,6 +96,7 @@ struct vk_ctx {
     uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
+    bool spill_force_wide = false; // VKIMG_SPILL_FORCE_WIDE=1: every k = 8, 9 replay job through the u32 window counters (tests)
     bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
 };
 
@@ -205,7 +206,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
     if (runs >= (1u << 24)) return VK_EINVAL;             // a run number travels in 24 bits (64 GiB of entries per sample)
     constexpr size_t kBucketHistBytes = static_cast<size_t>(kQueues) * (2u << (2 * K - 4)) * sizeof(uint32_t);  // pass B -> merge
-    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + 2 * kQueues * sizeof(uint32_t) + kBucketHistBytes;
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + 3 * kQueues * sizeof(uint32_t) + kBucketHistBytes;
     // never plan for more than three quarters of what is free (plus what this context already holds)
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -215,9 +216,9 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     uint32_t batch = static_cast<uint32_t>(budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
-    // workspace: cursors[batch] | hdrs[batch][runs] | bucket sizes[batch][16] | job order[batch * 16] |
+    // workspace: cursors[batch] | hdrs[batch][runs] | bucket sizes[batch][16] | job order[batch * 16] | wide flags[batch * 16] |
     //            bucket histograms[batch][16][2 * 4^K / 16] | arena[batch][runs][4 KiB]
-    const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs + 2 * kQueues)) * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs + 3 * kQueues)) * sizeof(uint32_t) + 255) / 256 * 256;
     const size_t bh_bytes = static_cast<size_t>(batch) * kBucketHistBytes;
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap,
                     head_bytes + bh_bytes + static_cast<size_t>(batch) * runs * kRunBytes);
@@ -227,6 +228,8 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     bp.hdrs = ctx->d_spill + batch;
     bp.bsize = bp.hdrs + static_cast<size_t>(batch) * runs;
     bp.order = bp.bsize + static_cast<size_t>(batch) * kQueues;
+    bp.wide = bp.order + static_cast<size_t>(batch) * kQueues;
+    bp.force_wide = ctx->spill_force_wide ? 1u : 0u;
     bp.bucket_hist = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes);
     bp.arena = reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes + bh_bytes;
     bp.runs_cap = static_cast<uint32_t>(runs);
@@ -254,6 +257,9 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         hipLaunchKernelGGL(vk_bucket_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bp, n * kQueues);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_bucket_count_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp);
+        VK_HIP(ctx, hipGetLastError());
+        // (jobs whose u16 pair counters wrapped: replayed into u32 window counters; every other workgroup leaves at once)
+        hipLaunchKernelGGL((vk_bucket_count_wide_kernel<K>), dim3(n * kQueues), dim3(kCountThreads), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_bucket_merge_kernel<K>), dim3(n * (NCODE / 256)), dim3(256), 0, ctx->stream, bp,
                            d_hist + static_cast<size_t>(s0) * NCODE);
@@ -325,6 +331,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
+        const char* fw = getenv("VKIMG_SPILL_FORCE_WIDE");
+        ctx->spill_force_wide = fw && fw[0] == '1';
         const char* kc = getenv("VKIMG_K1_CLASSIC");
         ctx->k1_classic = kc && kc[0] == '1';
     }

@@ -197,7 +197,7 @@ int count_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, u
 // handed through the 64-granule exchange buffer in file order (start tag on bit 7 of the first byte),
 // rounds of 64, the pending granules counted before a piece takes the general path, context from the
 // previous granule of the stream.  `stats` (optional): [0] pieces on the fast path, [1] pieces in all,
-// [2] rounds, [3] granules counted in rounds, [4] lanes described explicitly.
+// [2] rounds, [3] granules counted in rounds, [4] lanes set aside.
 template <int K>
 int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* hist, uint32_t* status, uint64_t* stats) {
     const uint32_t ncode = 1u << (2 * K);
@@ -231,6 +231,8 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
             const uint64_t span = w1 - o0;
             const uint32_t npieces = (uint32_t)((span + kPiece - 1) / kPiece);
             uint32_t ctx_c = 0, ctx_bad = 0x55555555u, pph = 0, npend = 0;
+            std::vector<uint32_t> alist;   // lanes set aside
+            bool aside63 = false;
             Granule xb[64];
             auto round = [&](uint32_t n) {  // xb[0 .. n) are real, lanes beyond idle along on newlines
                 uint32_t C[64], bad[64];
@@ -238,9 +240,8 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                     Granule q = {{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}};
                     if (lane < n) q = xb[lane];
                     uint32_t IV, SEQ;
-                    vkl::classify_granule(q.a[0] & ~(vkl::kGranuleStartTag | vkl::kGranuleAllTag), q.a[1], q.a[2], q.a[3],
+                    vkl::classify_granule(q.a[0] & ~vkl::kGranuleStartTag, q.a[1], q.a[2], q.a[3],
                                           (q.a[0] & vkl::kGranuleStartTag) != 0u, C[lane], IV, SEQ);
-                    if (q.a[0] & vkl::kGranuleAllTag) SEQ = 0xFFFFFFFFu;
                     bad[lane] = (IV | ~SEQ) & 0x55555555u;
                 }
                 for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -268,30 +269,36 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         if (vkl::ascii_or(d)) fast = false;
                     }
                 }
+                bool plainl[64];
                 if (fast) {
-                    uint32_t excl = 0;
-                    bool all_plain = true;
+                    uint32_t excl = 0, na = 0, lphs[64];
                     for (int lane = 0; lane < 64; ++lane) {
                         uint32_t d[16], mlo, mhi;
                         memcpy(d, piece + 64 * lane, 64);
                         vkl::newline_mask64(d, mlo, mhi);
                         const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
-                        const uint32_t lph = (pph + excl) & 3u;
+                        lphs[lane] = (pph + excl) & 3u;
                         excl += c;
-                        if (!vkl::seq_span(mlo, mhi, c, lph, sp[lane], ep[lane])) {
-                            // described explicitly: everything outside its sequence lines blanked, granules sent whole
-                            uint32_t plo, phi;
-                            vkl::phase1_mask64(mlo, mhi, lph, plo, phi);
-                            vkl::blank_outside(d, plo, phi);
-                            if (vkl::explicit_span(plo, phi, sp[lane], ep[lane]))
-                                for (uint32_t g = sp[lane] >> 4; g <= (ep[lane] >> 4); ++g) d[4 * g] |= vkl::kGranuleAllTag;
-                            memcpy(piece + 64 * lane, d, 64);
-                            if (stats) stats[4]++;
-                        }
+                        plainl[lane] = vkl::seq_span(mlo, mhi, c, lphs[lane], sp[lane], ep[lane]);
+                        na += plainl[lane] ? 0u : 1u;
                     }
                     total = excl;
-                    (void)all_plain;
+                    if (na > 6) fast = false;    // kSetAside
+                    else {
+                        // lanes set aside: a separator granule in the stream, an entry in the wave's list
+                        for (int lane = 0; lane < 64; ++lane) {
+                            if (plainl[lane]) continue;
+                            const bool before = lane == 0 ? aside63 : !plainl[lane - 1];
+                            alist.push_back(((it * 64u + (uint32_t)lane) << 3) | (before ? 4u : 0u) | lphs[lane]);
+                            memset(piece + 64 * lane, '\n', 16);
+                            sp[lane] = 0;
+                            ep[lane] = 15;
+                            if (stats) stats[4]++;
+                        }
+                        aside63 = !plainl[63];
+                    }
                 }
+                if (!fast) aside63 = false;
                 if (fast) {
                     if (stats) stats[0]++;
                     // the stream of this piece's granules, behind the pending ones; 64 at a time
@@ -355,6 +362,37 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                 pph += total;
             }
             if (npend != 0) return 2;  // cannot happen: the last piece of a range takes the general path
+            // the lanes set aside, counted exactly (vk_count.h set_aside_count): three blocks per entry through the
+            // front end of the classic kernel; every window that touches the lane
+            for (uint32_t w : alist) {
+                const uint64_t blk = w >> 3;
+                uint32_t cprev = 0, carry_bad = 0x55555555u, carry_c = 0;
+                for (uint32_t j = 0; j < 3; ++j) {
+                    uint8_t bytes[64];
+                    for (int i = 0; i < 64; ++i) {
+                        const uint64_t rel = (blk - 1 + j) * 64 + i;
+                        bytes[i] = rel < span ? s[o0 + rel] : 0;
+                    }
+                    uint32_t d[16];
+                    memcpy(d, bytes, 64);
+                    vkl::LaneBits lb;
+                    const uint32_t c = vkl::classify<false>(d, lb);
+                    const uint32_t lph = ((w & 3u) + (j == 0 ? 0u - c : (j == 2 ? cprev : 0u))) & 3u;
+                    cprev = c;
+                    const vkl::Mask128 seq = vkl::seq_mask_general(lb.NL, lph);
+                    uint32_t bad[4], ok[4];
+                    vkl::bad_mask(lb, seq, bad);
+                    vkl::ok_mask<K>(carry_bad, bad, ok);
+                    const uint32_t ch = carry_c;
+                    carry_bad = bad[3];
+                    carry_c = lb.C[3];
+                    const uint32_t kBack = (1u << (2 * (K - 1))) - 1u;
+                    if (j == 0) ok[0] = ok[1] = ok[2] = ok[3] = 0;
+                    if (j == 1 && (w & 4u)) ok[0] &= ~kBack;
+                    if (j == 2) { ok[0] &= kBack; ok[1] = ok[2] = ok[3] = 0; }
+                    vkl::windows<K>(ch, lb.C, ok, [&](uint32_t a4) { raw[a4 >> 2]++; }, [] {});
+                }
+            }
             prev_end = pph & 3u;
         }
     if (len) {

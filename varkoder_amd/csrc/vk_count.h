@@ -955,11 +955,83 @@ __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 
     return st;
 }
 
+// ---- lanes set aside --------------------------------------------------------------------------------
+// A lane whose 64 bytes the line pass cannot describe as one tagged stretch of granules (vkl::seq_span: four or
+// more newlines, reads under ~20-45 bases) does not send the piece down the general path: the lane puts ONE granule
+// of newlines into the stream in place of its own -- a separator: no window of the stream reaches into or across the
+// lane -- and leaves a word in the wave's list (kSetAside per piece at most, else the piece does take the general
+// path).  Behind the count kernel vk_aside_kernel counts the listed lanes exactly, a wavefront per list, 21 entries at
+// a time: three lanes per entry load the 64 bytes before the lane, the lane's and the 64 behind it, and go through the
+// front end of vk_count_kernel (every byte classified, any number of newlines); what is counted is every window that touches the
+// lane: all that end in it -- not those that reach back into a lane before it that was set aside itself, which that
+// lane's entry has counted -- and those that end in the first K - 1 positions behind it.
+// Entry: (block offset from the range's first piece) << 3 | (the lane before was set aside) << 2 | line phase at the lane.
+constexpr uint32_t kSetAside = 6;         // lanes of one piece that may be set aside
+constexpr uint32_t kSetAsideBatch = 21;   // entries a wavefront counts at a time (three lanes each)
+
+// One wavefront per wave of the count launch that left a list: vk_aside_kernel<K><<<grid * kWaves / 4, 256>>>, behind
+// the count kernel in the stream (its histogram rows are stored by then; the windows found here are added with global
+// atomics -- a few thousand per sample).  The deferred count as a function of the count kernel itself, called or
+// inlined behind its piece loop, made the K = 5 build lose the counts of that loop (gfx950, ROCm 7.2; not understood:
+// the same source was exact for K = 6, 7 and for K = 5 as soon as the function's adds were compiled out).
+template <int K>
+__global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+                                                        const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+                                                        uint32_t* __restrict__ hist_out, const uint32_t* __restrict__ aside,
+                                                        uint32_t aside_cap, const uint32_t* __restrict__ aside_n) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);   // wave of the count launch: unit * kWaves + wave
+    if (gw >= nsamples * parts * kWaves) return;
+    const uint32_t naside = aside_n[gw];
+    if (naside == 0u) return;
+    const uint32_t unit = gw / kWaves, wave = gw % kWaves;
+    const uint32_t smp = unit / parts, part = unit % parts;
+    const WaveRange wr = wave_range(lens[smp], parts, part, static_cast<int>(wave));
+    const uint8_t* sbase = fastq + offs[smp];
+    const uint64_t o0 = wr.w0 != 0 ? wr.w0 - 64 : 0;
+    const uint64_t span = wr.w1 - o0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(sbase + o0), 0, static_cast<int>((span + 15) & ~15ull), 0x00020000);
+    const uint32_t* list = aside + static_cast<uint64_t>(gw) * aside_cap;
+    uint32_t* hist = hist_out + static_cast<uint64_t>(smp) * NCODE;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ent = lane / 3u, j = lane - 3u * ent;
+    for (uint32_t at = 0; at < naside; at += kSetAsideBatch) {
+        const uint32_t n = naside - at < kSetAsideBatch ? naside - at : kSetAsideBatch;
+        const bool live = ent < n;
+        const uint32_t w = live ? list[at + ent] : 0u;
+        // (the lane's block is never the range's first: pieces 1 .. are the line pass's)
+        const uint32_t off = live ? ((w >> 3) - 1u + j) * 64u : 0xFFFFFF00u;   // beyond the range: zeros
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 0);
+        const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 32, 0);
+        const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 48, 0);
+        const uint32_t d[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w, e4.x, e4.y, e4.z, e4.w};
+        vkl::LaneBits lb;
+        const uint32_t c = vkl::classify<false>(d, lb);
+        const uint32_t cprev = wave_prev_lane(c, 0u);
+        const uint32_t lph = ((w & 3u) + (j == 0u ? 0u - c : (j == 2u ? cprev : 0u))) & 3u;
+        const vkl::Mask128 seq = vkl::seq_mask_general(lb.NL, lph);
+        uint32_t bad[4], ok[4];
+        vkl::bad_mask(lb, seq, bad);
+        const uint32_t badh = wave_prev_lane(bad[3], 0x55555555u);
+        const uint32_t ch = wave_prev_lane(lb.C[3], 0u);
+        vkl::ok_mask<K>(badh, bad, ok);
+        constexpr uint32_t kBack = (1u << (2 * (K - 1))) - 1u;   // OK bits of the windows that reach into the block before
+        if (!live || j == 0u) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+        if (j == 1u && (w & 4u) != 0u) ok[0] &= ~kBack;
+        if (j == 2u) { ok[0] &= kBack; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+        vkl::windows<K>(ch, lb.C, ok, [&](uint32_t field4) { atomicAdd(&hist[pair_reverse(field4 >> 2, K)], 1u); }, [] {});
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush) {
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush,
+    uint32_t* __restrict__ aside, uint32_t aside_cap, uint32_t* __restrict__ aside_n) {   // aside[grid * kWaves][aside_cap]: the waves' lists of lanes set aside; aside_n[grid * kWaves]: their lengths
     constexpr uint32_t NCODE = 1u << (2 * K);
     static_assert(NCODE <= kMaxBins, "LDS histogram too large");
     __shared__ uint32_t hist[NCODE];       // raw-field order, as in vk_count_kernel
@@ -976,7 +1048,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     __syncthreads();
 
     const WaveRange wr = wave_range(lens[smp], parts, part, wave);
-    uint32_t ph_start = 0, ph_end = 0, general_pieces = 0;
+    uint32_t ph_start = 0, ph_end = 0, general_pieces = 0, aside_count = 0;
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
@@ -1024,6 +1096,9 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         bool hot = false;
         uint32_t tick = 0;    // calls of the low-complexity probe
         uint32_t ngeneral = 0;  // pieces that took the general path (reported in the wave's phase word, bits 8..31)
+        uint32_t* const alist = aside + (static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)) * aside_cap;
+        uint32_t naside = 0;    // entries in alist
+        bool aside63 = false;   // lane 63 of the piece before was set aside
 
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
@@ -1033,9 +1108,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             return;
 #endif
             uint32_t C, IV, SEQ;
-            vkl::classify_granule(q.x & ~(vkl::kGranuleStartTag | vkl::kGranuleAllTag), q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
-            // (a granule of an explicitly described lane: everything in it that is not a newline is sequence)
-            SEQ |= static_cast<uint32_t>(static_cast<int32_t>(q.x << 16) >> 31);
+            vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
             const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
             const uint32_t badh = wave_prev_lane(bad, ctx_bad);
             const uint32_t ch = wave_prev_lane(C, ctx_c);
@@ -1092,31 +1165,31 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 total = lane_bcast(incl, 63);
                 const uint32_t lph = (pph + incl - c) & 3u;
                 const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e);
-                if (__any(!plain)) {
-                    // Lanes one tagged stretch of granules cannot describe (four or more newlines in 64 bytes, a read under
-                    // 15 bases inside one granule): their line-phase-1 positions found newline by newline, every other byte
-                    // of the lane turned into a newline IN THE PIECE'S REGISTERS, and the granules from the first to the
-                    // last one with such a position sent with kGranuleAllTag.  Rare (reads under ~20-45 bases), exact for
-                    // any text; the lanes beside them stay on the fast path.
-                    if (!plain) {
-                        uint32_t plo, phi, dd[16];
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) dd[i] = d[i];
-                        vkl::phase1_mask64(mlo, mhi, lph, plo, phi);
-                        vkl::blank_outside(dd, plo, phi);
-                        if (vkl::explicit_span(plo, phi, s, e)) {
-                            const uint32_t g0 = s >> 4, g1 = e >> 4;
-#pragma unroll
-                            for (uint32_t g = 0; g < 4; ++g)
-                                if (g >= g0 && g <= g1) dd[4 * g] |= vkl::kGranuleAllTag;
+                const unsigned long long am = __ballot(!plain);
+                if (am != 0ull) {   // rare: lanes set aside (see above), or too many of them
+                    const uint32_t na = static_cast<uint32_t>(__builtin_popcountll(am));
+#ifdef VK_DIAG_NO_ASIDE   // diagnostic build: every such piece down the general path, as before round 4
+                    if (true) {
+#else
+                    if (na > kSetAside || naside + na > aside_cap) {
+#endif
+                        fast = false;
+                    } else {
+                        if (!plain) {
+                            const uint32_t ln = lane_now();
+                            const bool before = ln == 0u ? aside63 : ((am >> (ln - 1u)) & 1ull) != 0ull;
+                            alist[naside + static_cast<uint32_t>(__builtin_popcountll(am & ((1ull << ln) - 1ull)))] =
+                                ((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph;
+                            r0 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);   // the separator
+                            s = 0u;
+                            e = 15u;
                         }
-                        r0 = make_uint4(dd[0], dd[1], dd[2], dd[3]);
-                        r1 = make_uint4(dd[4], dd[5], dd[6], dd[7]);
-                        r2 = make_uint4(dd[8], dd[9], dd[10], dd[11]);
-                        r3 = make_uint4(dd[12], dd[13], dd[14], dd[15]);
+                        naside += na;
                     }
                 }
+                if (fast) aside63 = (am >> 63) != 0ull;
             }
+            if (!fast) aside63 = false;
             if (!fast) {
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
                 // classified at once -- would spill the fast path's loop invariants) ----
@@ -1187,6 +1260,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         }
         ph_end = pph & 3u;
         general_pieces = ngeneral < 0xFFFFFFu ? ngeneral : 0xFFFFFFu;
+        aside_count = naside;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
 #ifdef VK_STAMPS
         if (lane == 0 && (blockIdx.x & 63u) == 0u) {  // [5] wait for the piece's bytes, [6] whole iterations, [7] pieces
@@ -1196,7 +1270,10 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         }
 #endif
     }
-    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2) | (general_pieces << 8));
+    if (lane == 0) {
+        wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2) | (general_pieces << 8));
+        aside_n[unit * kWaves + wave] = aside_count;   // (vk_aside_kernel counts the listed lanes)
+    }
 
     __syncthreads();
     uint32_t* out = hist_out + static_cast<uint64_t>(smp) * NCODE;

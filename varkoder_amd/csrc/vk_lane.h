@@ -542,79 +542,30 @@ VKL_FN uint32_t first_bit64(uint32_t lo, uint32_t hi) {  // index of the lowest 
 // The lane's stretch [s, e] of positions whose line phase is 1 (e = the newline that ends the sequence
 // line, 64 if it lies beyond the block; s = 64: none), from the newline mask, the newline count c and
 // the line phase lph at the block start: the stretch begins behind the dn-th newline, dn = the line ends
-// still to pass (0 .. 3), and ends at the next one.  Handles blocks with at most three newlines -- whatever
-// the phase: a block that begins in a quality line and holds that line's end and a whole header line (a
-// header under 64 bytes: every FASTQ whose records are not a multiple of 64 bytes has such blocks all
-// over) is as ordinary as one that begins in a header.  Returns false for what one stretch of granules with
-// a start tag cannot describe -- four or more newlines (reads shorter than ~20-45 bases, by the header's
-// length), a granule (16 positions) that holds both the start of a sequence line (not at its first
-// position) and the end of that line (reads under 15 bases), or one that holds two line ends in front of
-// the start (headers under 15 bytes): the caller describes such a lane
-// explicitly (phase1_mask64 / blank_outside / explicit_span below).
+// still to pass (0 .. 3), and ends at the next one.  A block that begins in a quality line and holds that
+// line's end and a whole header line (a header under 64 bytes: every FASTQ whose records are not a
+// multiple of 64 bytes has such blocks all over) is as ordinary as one that begins in a header.
+// Returns false for what one stretch of granules with a start tag cannot describe: four or more newlines,
+// or three with the stretch behind the second (reads shorter than ~20-45 bases, by the header's length);
+// a granule (16 positions) that holds both the start of a sequence line (not at its first position) and
+// the end of that line (reads under 15 bases); a granule that holds two line ends in front of the start
+// (headers under 15 bytes).  The caller counts the windows of such a lane apart (vk_count.h, "lanes set
+// aside").
 VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e) {
     const uint32_t dn = (1u - lph) & 3u;  // line ends to pass before a sequence line starts
     const uint32_t p1 = first_bit64(lo, hi);
     const uint32_t lo1 = lo & (lo - 1u), hi1 = lo ? hi : (hi & (hi - 1u));
     const uint32_t p2 = first_bit64(lo1, hi1);
-    const uint32_t lo2 = lo1 & (lo1 - 1u), hi2 = lo1 ? hi1 : (hi1 & (hi1 - 1u));
-    const uint32_t p3 = first_bit64(lo2, hi2);
-    // the five candidates (-1, p1, p2, p3, 64) in consecutive bytes; a funnel shift by 8 dn picks (start - 1, end)
-    const uint32_t cand = 0xFFu | (p1 << 8) | (p2 << 16) | (p3 << 24);
+    // the candidates (-1, p1, p2, 64, 64) in consecutive bytes; a funnel shift by 8 dn picks (start - 1, end)
+    const uint32_t cand = 0xFFu | (p1 << 8) | (p2 << 16) | (64u << 24);
     const uint32_t pr = alignbit(64u, cand, 8u * dn);
     s = umin(((pr & 0xFFu) + 1u) & 0xFFu, 64u);
     e = (pr >> 8) & 0xFFu;
     const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64: s & 15 == 0)
-    // A tagged granule's sequence bytes are those behind its FIRST newline: when the line end before the one the
-    // stretch starts behind lies in the same granule (a header under 15 bytes behind the end of a quality line),
-    // the tag cannot say it.  (dn = 1: the byte picked is the -1 candidate, 0xFF, never a granule of the block.)
-    const uint32_t before = (cand >> ((8u * dn - 8u) & 31u)) & 0xFFu;
-    const bool two = dn >= 2u && (s & 15u) != 0u && (before >> 4) == ((s - 1u) >> 4);
-    return c <= 3u && !both && !two;
-}
-
-// -- lanes seq_span refuses, described explicitly (rare: the wave runs this under a uniform branch) --------
-// Bit p of {hi, lo} set <=> position p has line phase 1, the newline that ends the sequence line included; any
-// number of newlines.  One step per newline of the block.
-VKL_FN void phase1_mask64(uint32_t nlo, uint32_t nhi, uint32_t lph, uint32_t& plo, uint32_t& phi) {
-    uint64_t m = (static_cast<uint64_t>(nhi) << 32) | nlo, P = 0;
-    uint32_t cur = lph & 3u, pos = 0;
-    while (m != 0ull) {
-        const uint32_t nxt = ffbl(static_cast<uint32_t>(m)) < 32u ? ffbl(static_cast<uint32_t>(m)) : 32u + ffbl(static_cast<uint32_t>(m >> 32));
-        if (cur == 1u) P |= (nxt == 63u ? ~0ull : ((1ull << (nxt + 1u)) - 1ull)) & ~((1ull << pos) - 1ull);
-        pos = nxt + 1u;
-        cur = (cur + 1u) & 3u;
-        m &= m - 1ull;
-    }
-    if (cur == 1u && pos < 64u) P |= ~((1ull << pos) - 1ull);
-    plo = static_cast<uint32_t>(P);
-    phi = static_cast<uint32_t>(P >> 32);
-}
-
-// Every byte of the block whose position is not in {phi, plo} becomes a newline: what is left is sequence-line
-// bytes between newlines, and a granule of it needs no line logic at all (kGranuleAllTag).
-VKL_FN void blank_outside(uint32_t d[16], uint32_t plo, uint32_t phi) {
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t m4 = ((i < 8 ? plo : phi) >> (4 * (i & 7))) & 15u;
-        const uint32_t keep = ((m4 * 0x00204081u) & 0x01010101u) * 0xFFu;   // bit j of m4 -> byte j
-        d[i] = (d[i] & keep) | (0x0A0A0A0Au & ~keep);
-    }
-}
-
-// The granules of an explicitly described lane: from the first to the last one that holds a position of
-// {phi, plo}, as a span (s = 16 x first, no start tag; e = the last one's last position); false: none.
-VKL_FN bool explicit_span(uint32_t plo, uint32_t phi, uint32_t& s, uint32_t& e) {
-    s = 64u;
-    e = 64u;
-    if ((plo | phi) == 0u) return false;
-    const uint32_t first = plo ? ffbl(plo) : 32u + ffbl(phi);
-    uint32_t last = 0;
-    for (uint32_t g = 0; g < 4; ++g) {
-        const uint32_t bits = ((g < 2 ? plo : phi) >> (16u * (g & 1u))) & 0xFFFFu;
-        if (bits) last = g;
-    }
-    s = (first >> 4) << 4;
-    e = 16u * last + 15u;
-    return true;
+    // A tagged granule's sequence bytes are those behind its FIRST newline: with dn = 2 the line end before the one
+    // the stretch starts behind (p1) must lie in an earlier granule.
+    const bool two = dn == 2u && (s & 15u) != 0u && (p1 >> 4) == (p2 >> 4);
+    return c <= (dn >= 2u ? 2u : 3u) && !both && !two;
 }
 
 // The granules of a lane that go to the heavy stage: every granule with a position of line phase 1,
@@ -628,9 +579,6 @@ VKL_FN uint32_t span_count(uint32_t s, uint32_t e) { return s < 64u ? span_last(
 // of its first byte set (the bytes are ASCII); every other granule's sequence bytes are those before
 // its first newline, or all of them.
 constexpr uint32_t kGranuleStartTag = 0x80u;
-// A granule of an explicitly described lane (blank_outside) travels with bit 7 of its SECOND byte set: every byte of it
-// that is not a newline is a sequence byte.
-constexpr uint32_t kGranuleAllTag = 0x8000u;
 VKL_FN bool span_starts_inside(uint32_t s) { return s < 64u && (s & 15u) != 0u; }
 
 // Heavy stage, one all-ASCII granule (start tag already taken off): codes, invalid flags and the

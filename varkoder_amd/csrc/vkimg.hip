@@ -62,6 +62,8 @@ struct vk_ctx {
     uint32_t desc_n = 0;
     uint32_t* d_wavephase = nullptr;
     size_t wavephase_cap = 0;
+    uint32_t* d_aside = nullptr;  // k <= 7: the waves' lists of lanes set aside
+    size_t aside_cap = 0;
     uint32_t* d_scratch = nullptr;
     size_t scratch_cap = 0;
     uint32_t* d_spill = nullptr;  // k >= 8: bucket cursors + bucket streams
@@ -169,7 +171,7 @@ uint32_t npad_of(uint32_t npix) {
 
 template <int K>
 int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
-                 uint32_t nsamples, uint32_t parts, uint64_t /*maxlen*/, uint32_t* d_hist, const SubParams* sub) {
+                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub) {
     const uint32_t grid = nsamples * parts;
     const int atomic_flush = parts > 1 ? 1 : 0;
     if (atomic_flush)
@@ -186,8 +188,22 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
     else {
         ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * 1024;
+        // the waves' lists of lanes set aside (vk_count.h): room for one lane in every second piece of the longest
+        // range, at least 64 entries; a wave whose list is full sends its pieces down the general path instead
+        const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
+        uint64_t cap = wave_bytes / (2 * kPiece) + 64;
+        if (cap > (1u << 20)) cap = 1u << 20;
+        const size_t nwaves = static_cast<size_t>(grid) * kWaves;
+        const size_t need = nwaves * (cap + 1) * sizeof(uint32_t);   // lists, then their lengths
+        int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_aside), &ctx->aside_cap, need);
+        if (rc) return rc;
+        uint32_t* const d_aside_n = ctx->d_aside + nwaves * cap;
         hipLaunchKernelGGL((vk_count_dense_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush);
+                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
+                           static_cast<uint32_t>(cap), d_aside_n);
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((vk_aside_kernel<K>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
+                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n);
     }
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
@@ -357,7 +373,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc, ctx->d_synth, ctx->d_synth_offs};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc, ctx->d_synth, ctx->d_synth_offs, ctx->d_aside};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);

@@ -327,6 +327,29 @@ def test_spill_replay_pair_counters_wrap_and_the_wide_replay_takes_over(engines,
         e2.close()
 
 
+@pytest.mark.parametrize("k", (8, 9))
+def test_spill_path_through_the_packed_stream(k, monkeypatch):
+    """VKIMG_SPILL_PACKED=1: pass A of k = 8, 9 as vk_pack_kernel (the text packed into 2-bit codes + masks, lanes the
+    line pass cannot describe set aside and counted by vk_aside_kernel) + the partition of the packed stream --
+    slower than the shipped single kernel for a plain count, but the same histogram: synthetic batches of all three
+    read shapes, the edge cases, several workgroup splits."""
+    from varkoder_amd.engine import ImageEngine
+    monkeypatch.setenv("VKIMG_SPILL_PACKED", "1")
+    eng = ImageEngine(k=k, mapping="cgr", device=0)
+    try:
+        samples = [synth.sample_fastq(50 + i, 8000, 150, dist=i % 3) for i in range(6)] + list(edge_cases().values())
+        want = [oracle.count_fastq(s, k)[0] for s in samples]
+        dev, offs, lens = eng.upload(samples)
+        for parts in (0, 1, 3):
+            hist, status = eng.count(dev, offs, lens, parts=parts)
+            assert not status.cpu().numpy().any(), parts
+            got = hist.cpu().numpy().view(np.uint32)
+            for i in range(len(samples)):
+                assert np.array_equal(got[i], want[i]), (parts, i)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("k", KS)
 def test_count_fuzz_batches(engines, k):
     """Hundreds of random adversarial (well-formed) FASTQ samples per launch, random workgroup

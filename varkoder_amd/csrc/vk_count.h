@@ -1287,6 +1287,22 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     }
 }
 
+// ---- the packed sequence stream (written by vk_pack_kernel, vk_pack.h) --------------------------------
+constexpr uint32_t kPackHasPre = 0x80000000u;   // count word: the segment opens with a record of context
+constexpr uint32_t kPackBlock = 256;            // records a consumer wavefront takes at a time (four per lane)
+
+struct PackParams {
+    uint32_t* c;            // codes of every record of the launch
+    uint32_t* m;            // masks: even bits BAD, odd bits SITE
+    const uint64_t* base;   // [nsamples] first record of the sample's region (a multiple of 4)
+    uint32_t* count;        // [nsamples * parts * kWaves] records of the wave's segment | kPackHasPre
+};
+
+// first record of the segment of wave `wave` of workgroup `part` (a multiple of 4: the consumers load four records per lane)
+__device__ __forceinline__ uint64_t pack_segment(const PackParams& pk, uint32_t smp, uint32_t part, int wave, uint64_t w0) {
+    return pk.base[smp] + (w0 >> 4) + 8ull * (static_cast<uint64_t>(part) * kWaves + static_cast<uint32_t>(wave));
+}
+
 // ---- K = 8, 9: the LDS-spill path ------------------------------------------------------
 // 4^K u32 counters do not fit LDS.  Pass A (vk_bucket_kernel) streams the FASTQ exactly like
 // vk_count_kernel, but instead of counting it PARTITIONS the windows into 16 bucket streams per
@@ -1370,11 +1386,14 @@ __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane 
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
 }
 
-template <int K, bool SUB>
-__global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_kernel(
+// MODE 0: the FASTQ text through vk_count_kernel's front end (every byte classified); 1: the same with read
+// subsampling; 2: the packed stream of vk_pack_kernel (no line logic, no classification here: the shipped pass A).
+template <int K, int MODE>
+__global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_bucket_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp) {
+    uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp, PackParams pk) {
+    constexpr bool SUB = MODE == 1, STREAM = MODE == 2;
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr uint32_t LB = 2 * K - 4;               // bits of an entry that come from the shared prefix
     constexpr uint32_t LMASK = (1u << LB) - 1u;
@@ -1633,10 +1652,10 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
                     hot = repeats_dominate(handled, ok_);
                 }
             }
-            if constexpr (SUB) {
+            if constexpr (SUB || STREAM) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (__any(okl[g] != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common
+                    if (__any(okl[g] != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common (MODE 1)
                         append_group(v[g], v[g + 1], okl[g]);
                         if (g == 1) maybe_drain(kDrainAt);  // inside a piece only a queue that is filling up fast is drained (skewed bases)
                     }
@@ -1695,10 +1714,52 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
             sw.seed = sp.seeds[s];
             sw.threshold = sp.thresholds[s];
         }
-        wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
-                                                piece_start, ph_start, ph_end, sw);
+        if constexpr (STREAM) {
+            // The wave's segment of the packed stream, kPackBlock records at a time, four consecutive records per lane:
+            // exactly the (codes of the 16 positions before, four code words, four OK words) a piece of the text front
+            // end hands to `win`, with every group holding sequence.  Records beyond the segment's end read as BAD.
+            const uint32_t cw = pk.count[unit * kWaves + static_cast<uint32_t>(wave)];
+            const uint32_t nrec = cw & ~kPackHasPre;
+            const uint64_t seg = pack_segment(pk, s, part, wave, wr.w0);
+            const uint4* const pc4 = reinterpret_cast<const uint4*>(pk.c + seg);
+            const uint4* const pm4 = reinterpret_cast<const uint4*>(pk.m + seg);
+            const uint32_t nblocks = (nrec + kPackBlock - 1u) / kPackBlock;
+            uint32_t carry_c = 0u, carry_bad = 0x55555555u;
+            uint4 c4 = make_uint4(0u, 0u, 0u, 0u), m4 = c4;
+            if (nblocks != 0u) {
+                c4 = pc4[lane];
+                m4 = pm4[lane];
+            }
+            for (uint32_t b = 0; b < nblocks; ++b) {
+                const uint4 cc = c4, mm = m4;
+                piece_start(cc);
+                if (b + 1u < nblocks) {   // the next block's loads fly under this one's appends
+                    c4 = pc4[(b + 1u) * 64u + static_cast<uint32_t>(lane)];
+                    m4 = pm4[(b + 1u) * 64u + static_cast<uint32_t>(lane)];
+                }
+                const uint32_t at = b * kPackBlock + 4u * static_cast<uint32_t>(lane);
+                const uint32_t cv[4] = {cc.x, cc.y, cc.z, cc.w}, mv[4] = {mm.x, mm.y, mm.z, mm.w};
+                uint32_t C[4], bad[4], ok[4];
+#pragma unroll
+                for (uint32_t g = 0; g < 4; ++g) {
+                    const bool in = at + g < nrec;
+                    C[g] = in ? cv[g] : 0u;
+                    bad[g] = in ? (mv[g] & 0x55555555u) : 0x55555555u;
+                }
+                const uint32_t badh = wave_prev_lane(bad[3], carry_bad);
+                const uint32_t ch = wave_prev_lane(C[3], carry_c);
+                carry_bad = lane_bcast(bad[3], 63);
+                carry_c = lane_bcast(C[3], 63);
+                vkl::ok_mask<K>(badh, bad, ok);
+                if (b == 0u && lane == 0 && (cw & kPackHasPre) != 0u) ok[0] = 0u;   // the record of context: its windows are the wave before's
+                win(ch, C, ok);
+            }
+        } else {
+            wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
+                                                    piece_start, ph_start, ph_end, sw);
+        }
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
-        if constexpr (!SUB) {
+        if constexpr (MODE == 0) {
             if (xpend != 0u) {  // the groups still waiting in the exchange buffer
                 const uint2* const xg = reinterpret_cast<const uint2*>(ldsb + kLdsXchg) + static_cast<uint32_t>(wave) * 64u;
                 uint2 e = make_uint2(0u, 0u);
@@ -1724,7 +1785,9 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_bucket_
             atomicAdd(&bp.bsize[s * kQueues + q], used);
         }
     }
-    if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+    if constexpr (!STREAM) {   // (MODE 2: vk_pack_kernel has written the waves' phase words)
+        if (lane == 0) wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2));
+    }
 }
 
 // Between pass A and pass B: the (sample, bucket) jobs of pass B ordered by size class (the power of two of

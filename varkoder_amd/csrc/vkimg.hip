@@ -38,6 +38,7 @@
 #include "vk_lane.h"
 
 #include "vk_count.h"
+#include "vk_pack.h"
 #include "vk_image.h"
 #include "vk_inflate.h"
 #include "vk_aux.h"
@@ -98,6 +99,7 @@ struct vk_ctx {
     uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
+    bool spill_packed = false;     // VKIMG_SPILL_PACKED=1: k = 8, 9 pass A in two kernels, vk_pack_kernel + the partition of the packed stream (measured slower than the one kernel that classifies every byte: 21.1 against 16.3 ms per 100 samples; tests, A/B timing)
     bool spill_force_wide = false; // VKIMG_SPILL_FORCE_WIDE=1: every k = 8, 9 replay job through the u32 window counters (tests)
     bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
 };
@@ -222,7 +224,11 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
     if (runs >= (1u << 24)) return VK_EINVAL;             // a run number travels in 24 bits (64 GiB of entries per sample)
     constexpr size_t kBucketHistBytes = static_cast<size_t>(kQueues) * (2u << (2 * K - 4)) * sizeof(uint32_t);  // pass B -> merge
-    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + 3 * kQueues * sizeof(uint32_t) + kBucketHistBytes;
+    // the packed stream of a sample (vk_pack.h): a record per 16 bytes of text at most, a few per wavefront on top
+    const bool packed = sub == nullptr && ctx->spill_packed;
+    const uint64_t pack_recs = packed ? ((maxlen + 15) / 16 + 8ull * parts * kWaves + 16 + 3) / 4 * 4 : 0;
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + sizeof(uint32_t)) + sizeof(uint32_t) + 3 * kQueues * sizeof(uint32_t) + kBucketHistBytes +
+                              pack_recs * 8 + 64;
     // never plan for more than three quarters of what is free (plus what this context already holds)
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -236,8 +242,12 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     //            bucket histograms[batch][16][2 * 4^K / 16] | arena[batch][runs][4 KiB]
     const size_t head_bytes = ((static_cast<size_t>(batch) * (1 + runs + 3 * kQueues)) * sizeof(uint32_t) + 255) / 256 * 256;
     const size_t bh_bytes = static_cast<size_t>(batch) * kBucketHistBytes;
+    const size_t arena_bytes = static_cast<size_t>(batch) * runs * kRunBytes;
+    // packed stream: codes | masks (+ a block of slack: the last wavefront's loads run to the end of its last block) | sample bases | counts
+    const size_t pack_arr = packed ? (static_cast<size_t>(batch) * pack_recs + kPackBlock) * sizeof(uint32_t) : 0;
+    const size_t pack_meta = packed ? (static_cast<size_t>(batch) * sizeof(uint64_t) + static_cast<size_t>(batch) * parts * kWaves * sizeof(uint32_t) + 255) / 256 * 256 : 0;
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap,
-                    head_bytes + bh_bytes + static_cast<size_t>(batch) * runs * kRunBytes);
+                    head_bytes + bh_bytes + arena_bytes + 2 * pack_arr + pack_meta);
     if (rc) return rc;
     BucketParams bp;
     bp.cursors = ctx->d_spill;
@@ -249,6 +259,30 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     bp.bucket_hist = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes);
     bp.arena = reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes + bh_bytes;
     bp.runs_cap = static_cast<uint32_t>(runs);
+    PackParams pk{};
+    uint32_t aside_cap = 0;
+    uint32_t* d_aside_n = nullptr;
+    if (packed) {
+        uint8_t* at = reinterpret_cast<uint8_t*>(ctx->d_spill) + head_bytes + bh_bytes + arena_bytes;
+        pk.c = reinterpret_cast<uint32_t*>(at);
+        pk.m = reinterpret_cast<uint32_t*>(at + pack_arr);
+        uint64_t* d_base = reinterpret_cast<uint64_t*>(at + 2 * pack_arr);
+        pk.base = d_base;
+        pk.count = reinterpret_cast<uint32_t*>(d_base + batch);
+        std::vector<uint64_t> base(batch);
+        for (uint32_t i = 0; i < batch; ++i) base[i] = static_cast<uint64_t>(i) * pack_recs;
+        VK_HIP(ctx, hipMemcpyAsync(d_base, base.data(), batch * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+        VK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (base is a temporary; once per call)
+        // the waves' lists of lanes set aside, as for the k <= 7 kernel
+        const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
+        uint64_t cap = wave_bytes / (2 * kPiece) + 64;
+        if (cap > (1u << 20)) cap = 1u << 20;
+        aside_cap = static_cast<uint32_t>(cap);
+        const size_t nwaves = static_cast<size_t>(batch) * parts * kWaves;
+        rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_aside), &ctx->aside_cap, nwaves * (cap + 1) * sizeof(uint32_t));
+        if (rc) return rc;
+        d_aside_n = ctx->d_aside + nwaves * cap;
+    }
     VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
     ctx->last_block = kCountThreads;
     ctx->last_lds = kLdsBucketBytes;
@@ -256,18 +290,28 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
         VK_HIP(ctx, hipMemsetAsync(ctx->d_spill, 0, head_bytes, ctx->stream));  // cursors and run headers
         ctx->last_grid = n * parts;
+        uint32_t* const hist0 = d_hist + static_cast<size_t>(s0) * NCODE;
+        uint32_t* const wph0 = ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves;
         if (sub) {
             SubParams sp = *sub;  // this sub-batch's slice of the per-sample arrays
             sp.seeds += s0;
             sp.thresholds += s0;
             if (sp.sites) sp.sites += 2ull * s0;
-            hipLaunchKernelGGL((vk_bucket_kernel<K, true>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
-                               d_fastq, d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
-                               ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, sp);
+            hipLaunchKernelGGL((vk_bucket_kernel<K, 1>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                               d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, sp, PackParams{});
+        } else if (packed) {
+            // pass A in two kernels: the text packed once (the k <= 7 kernel's front end), the stream partitioned
+            hipLaunchKernelGGL(vk_pack_kernel, dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs + s0,
+                               d_lens + s0, n, parts, pk, wph0, ctx->d_aside, aside_cap, d_aside_n);
+            VK_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL((vk_aside_kernel<K>), dim3((n * parts * kWaves + 3) / 4), dim3(256), 0, ctx->stream, d_fastq,
+                               d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n);
+            VK_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL((vk_bucket_kernel<K, 2>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                               d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, pk);
         } else {
-            hipLaunchKernelGGL((vk_bucket_kernel<K, false>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
-                               d_fastq, d_offs + s0, d_lens + s0, n, parts, d_hist + static_cast<size_t>(s0) * NCODE,
-                               ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves, bp, SubParams{});
+            hipLaunchKernelGGL((vk_bucket_kernel<K, 0>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                               d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, PackParams{});
         }
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(vk_bucket_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bp, n * kQueues);
@@ -347,6 +391,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
+        const char* tf = getenv("VKIMG_SPILL_PACKED");
+        ctx->spill_packed = tf && tf[0] == '1';
         const char* fw = getenv("VKIMG_SPILL_FORCE_WIDE");
         ctx->spill_force_wide = fw && fw[0] == '1';
         const char* kc = getenv("VKIMG_K1_CLASSIC");

@@ -707,6 +707,10 @@ def main():
                        "fastq_bytes_per_sample": fastq_bytes, "parallelism": "samples sharded x%d" % world,
                        "count_launch": eng.last_count_launch()},
             "ms_per_step_by_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            **({"rehearsal": "all %d ranks share cuda:0 (--all-on-device0): `value`, ms_per_step and the kernel times say nothing about "
+                             "N GPUs; what this run measures is the HOST side of a node-level run -- %d ranks' staging pools, page cache "
+                             "and H2D streams at once, with the I/O threads each rank gets of this box's cores (end_to_end)" % (world, world)}
+               if args.all_on_device0 and world > 1 else {}),
             "kernel_ms": {count_kernel + "(+check)": count_ms, "vk_image_kernel": image_ms},
             "bad_status_samples": bad,
             "roofline": {"bound": "hbm", "kernel": count_kernel, "achieved": achieved,

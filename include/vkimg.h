@@ -103,6 +103,26 @@ int vk_count_sampled_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* of
                             const uint64_t* thresholds, uint32_t* d_hist, uint32_t* d_status,
                             uint64_t* d_sites);
 
+/* The read index of a batch of samples resident in HBM: one streaming pass per sample that lists every read's
+ * anchor (the newline that ends its header line) and adds up the bytes of all sequence lines -- `nsites`, which
+ * split_fastq computes before it derives its ladder of subsample sizes (commands/image.py:663-675).  sites[i]
+ * and status[i] (VK_ST_* bits) are HOST arrays; the call synchronises.  The context keeps the index until the
+ * next call: vk_count_sampled_device calls whose samples (same d_fastq, same offsets and lengths, in any order
+ * and any number of times) are all in it then WALK the reads each subsample takes instead of streaming the text
+ * once per subsample (the reference runs reformat.sh + dsk once per subsample, :577-627, :682-695) -- same
+ * counts, same sites.  A sample with more than one read per 32 bytes of text, or of 4 GiB and more, gets no index
+ * (such calls stream as before).  VKIMG_NO_READ_INDEX=1 disables the walker. */
+int vk_read_index_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                         uint32_t nsamples, uint32_t parts_per_sample, uint64_t* sites, uint32_t* status);
+
+/* vk_count_device and vk_read_index_device in ONE pass over the text (k <= 7: the count kernel lists the anchors and
+ * adds up the sites on its way; k = 8, 9: the two passes, one after the other): what a ladder whose first step takes
+ * every read wants (split_fastq when the file holds less than --max-bp, commands/image.py:677-680).  d_hist /
+ * d_status as vk_count_device; sites / status (host) as vk_read_index_device; the call synchronises. */
+int vk_count_index_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
+                          uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status,
+                          uint64_t* sites, uint32_t* status);
+
 /* Replaces make_image()'s arithmetic = `dsk2ascii` dump + join/groupby +
  * count+1 scatter + 256-quantile rank binning (commands/image.py:864-919) for a
  * batch of histograms.  d_img[nsamples][npix] receives the uint8 pixels. */

@@ -113,6 +113,84 @@ def test_sampled_count_matches_the_oracle(k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [5, 7, 9])
+def test_read_index_and_walker_match_the_oracle(k):
+    """vk_read_index_device + the walker (vk_ladder.h): the same subsampled counts and sites as the streaming kernel and
+    the oracle, for the edge cases, all three synthetic read shapes (fixed 150, GC skew + homopolymers, fastp's 0 .. 290),
+    long reads across many 500-base breaks, several workgroup splits, the same sample under several (seed, threshold)
+    pairs in one call; nsites from the index equals the oracle's; a sample of reads too short for the index (more than one
+    per 32 bytes) falls back to the streaming kernel, still exact."""
+    eng = _engine(k)
+    cases = fastq_cases.edge_cases()
+    names = ["one_read", "n_in_middle", "lowercase", "crlf", "no_final_newline", "qual_starts_at_plus", "poly_a", "ragged", "long_read"]
+    blobs = [cases[n] for n in names]
+    blobs += [fastq_cases.random_fastq(np.random.default_rng(40 + s), 300) for s in range(3)]
+    blobs += [synth.sample_fastq(3 + d, 5000, 150, dist=d).tobytes() for d in range(3)]
+    blobs.append(b"".join(fastq_cases.rec(f"L{i}", fastq_cases.rand_seq(np.random.default_rng(i), 1700)) for i in range(60)))
+    fq, offs, lens = eng.upload(blobs)
+    for parts in (0, 1, 3):
+        nsites, status = eng.read_index(fq, offs, lens, parts=parts)
+        for i, blob in enumerate(blobs):
+            _, _, wst, wsites = oracle.count_fastq_sampled(blob, k, 0, 1 << 32)
+            assert status[i] == 0 and wst == 0 and int(nsites[i]) == wsites[0], (i, parts)
+        # every blob under three (seed, fraction) pairs, one launch
+        pairs = [(i, seed, frac) for i in range(len(blobs)) for seed, frac in ((7, 0.3), (8, 1.0), (9, 0.05))]
+        idx = [i for i, _, _ in pairs]
+        seeds = np.array([s_ for _, s_, _ in pairs], dtype=np.uint64)
+        thr = np.array([min(1 << 32, int(f * (1 << 32))) for _, _, f in pairs], dtype=np.uint64)
+        hist, st, sites = eng.count_sampled(fq, offs[idx], lens[idx], seeds, thr)
+        assert eng.last_count_launch()["grid"] % len(pairs) == 0      # one workgroup per (pair, part): the walker's grid
+        h = hist.cpu().numpy().view(np.uint32)
+        si = sites.cpu().numpy()
+        assert not st.cpu().numpy().any()
+        for j, (i, seed, frac) in enumerate(pairs):
+            want, nwin, wst, wsites = oracle.count_fastq_sampled(blobs[i], k, seed, int(thr[j]))
+            assert tuple(int(x) for x in si[j]) == wsites, (j, i, seed, frac, parts)
+            assert int(h[j].sum(dtype=np.uint64)) == nwin and np.array_equal(h[j], want), (j, i, seed, frac, parts)
+    # reads of a few bases: more anchors than the index holds -> no index for that sample, the call streams instead
+    tiny = b"".join(fastq_cases.rec("t", "ACGTAC") for i in range(4000))
+    fq2, o2, l2 = eng.upload([tiny, blobs[-1]])
+    nsites, status = eng.read_index(fq2, o2, l2)
+    assert int(nsites[0]) == 6 * 4000 and int(nsites[1]) == 1700 * 60
+    hist, st, sites = eng.count_sampled(fq2, o2, l2, 5, 1 << 31)
+    for i, blob in enumerate((tiny, blobs[-1])):
+        want, nwin, wst, wsites = oracle.count_fastq_sampled(blob, k, 5, 1 << 31)
+        assert np.array_equal(hist.cpu().numpy().view(np.uint32)[i], want) and tuple(int(x) for x in sites.cpu().numpy()[i]) == wsites
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [5, 6, 7, 8])
+def test_count_and_index_in_one_pass(k):
+    """vk_count_index_device: the plain count, the number of sites and the read index out of one pass over the text (k <= 7:
+    the count kernel lists the anchors on its way -- fast path, general path and the lanes set aside each add theirs);
+    subsamples walked from that index equal the oracle's, as from vk_read_index_device's."""
+    eng = _engine(k)
+    cases = fastq_cases.edge_cases()
+    blobs = [cases[n] for n in ("one_read", "crlf", "no_final_newline", "qual_starts_at_plus", "ragged", "long_read", "long_header")]
+    blobs += [fastq_cases.random_fastq(np.random.default_rng(70 + s), 300) for s in range(3)]
+    blobs += [synth.sample_fastq(13 + d, 6000, 150, dist=d).tobytes() for d in range(3)]
+    fq, offs, lens = eng.upload(blobs)
+    for parts in (0, 1, 4):
+        hist, nsites, status = eng.count_index(fq, offs, lens, parts=parts)
+        h = hist.cpu().numpy().view(np.uint32)
+        for i, blob in enumerate(blobs):
+            want, nwin, wst = oracle.count_fastq(blob, k)
+            _, _, _, wsites = oracle.count_fastq_sampled(blob, k, 0, 1 << 32)
+            assert status[i] == 0 and wst == 0 and np.array_equal(h[i], want), (i, parts)
+            assert int(nsites[i]) == wsites[0], (i, parts, int(nsites[i]), wsites[0])
+        idx = list(range(len(blobs))) * 2
+        seeds = np.array([3] * len(blobs) + [4] * len(blobs), dtype=np.uint64)
+        thr = np.array([1 << 30] * len(blobs) + [(1 << 32) // 50] * len(blobs), dtype=np.uint64)
+        sh, st, sites = eng.count_sampled(fq, offs[idx], lens[idx], seeds, thr)
+        for j, i in enumerate(idx):
+            want, nwin, wst, wsites = oracle.count_fastq_sampled(blobs[i], k, int(seeds[j]), int(thr[j]))
+            assert np.array_equal(sh.cpu().numpy().view(np.uint32)[j], want), (j, i, parts)
+            assert tuple(int(x) for x in sites.cpu().numpy()[j]) == wsites, (j, i, parts)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_sampling_fraction_and_seed_independence():
     eng = _engine(7)
     blob = synth.sample_fastq(11, 40000, 150, dist=0).tobytes()

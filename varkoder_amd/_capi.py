@@ -15,7 +15,7 @@ SYMBOLS = ("vk_abi_version", "vk_strerror", "vk_last_hip_error", "vk_ctx_create"
            "vk_ctx_sync", "vk_set_mapping", "vk_count_device", "vk_image_device",
            "vk_fastq_to_image_device", "vk_count_host", "vk_image_host", "vk_synth_fastq_device", "vk_remap_host", "vk_preprocess_device",
            "vk_last_count_launch", "vk_count_sampled_device", "vk_inflate_device", "vk_upload_mapped", "vk_host_register", "vk_host_unregister",
-           "vk_synth_shaped_lengths", "vk_synth_shaped_device", "vk_last_count_general")
+           "vk_synth_shaped_lengths", "vk_synth_shaped_device", "vk_last_count_general", "vk_read_index_device", "vk_count_index_device")
 
 _lib = None
 
@@ -54,6 +54,8 @@ def lib():
     L.vk_synth_fastq_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
     L.vk_synth_shaped_lengths.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u64p]
     L.vk_synth_shaped_device.argtypes = [vp, vp, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.vk_read_index_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_uint32, u64p, u32p]
+    L.vk_count_index_device.argtypes = [vp, vp, u64p, u64p, C.c_uint32, C.c_int, C.c_uint32, vp, vp, u64p, u32p]
     L.vk_last_count_general.argtypes = [vp, u64p, u64p]
     L.vk_last_count_launch.argtypes = [vp, u32p, u32p, u32p]
     L.vk_preprocess_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, C.c_float, C.c_float, vp]

@@ -813,6 +813,70 @@ __global__ __launch_bounds__(kCountThreads, SUB ? 4 : VK_K1_OCC) void vk_count_k
     }
 }
 
+// This lane's number, recomputed where it is needed (two v_mbcnt): the dense kernel's piece loop holds no
+// per-lane value across iterations besides the prefetched bytes -- what lives across the call of the
+// general path would otherwise sit in scratch and come back with a vmcnt(0) wait at every use.
+__device__ __forceinline__ uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// ---- the read index (vk_ladder.h; vk_count_dense_kernel<K, true> fills it on the way) ---------------------
+struct IndexParams {
+    uint32_t* anchors;        // anchor lists of every sample of the launch
+    const uint64_t* base;     // [nsamples] first entry of the sample's region
+    uint32_t* count;          // [nsamples * parts * kWaves] anchors in the wave's segment
+    unsigned long long* sites;  // [nsamples] bytes of all sequence lines
+    uint32_t* overflow;       // [nsamples] != 0: a segment was full (more than one read per 32 bytes): no index for this sample
+};
+
+// anchors a wavefront's segment holds: one per 32 bytes of its range (a record of 150-base reads is 320), and a few
+__device__ __host__ __forceinline__ uint64_t index_segment_cap(uint64_t range_bytes) { return range_bytes / 32 + 8; }
+
+// first entry of the segment of wave `wave` of workgroup `part`; bw = bytes per wave range (wave_range's, a multiple of 64)
+__device__ __forceinline__ uint64_t index_segment(const IndexParams& ip, uint32_t smp, uint64_t w0, uint32_t part, int wave) {
+    return ip.base[smp] + w0 / 32 + 8ull * (static_cast<uint64_t>(part) * kWaves + static_cast<uint32_t>(wave));
+}
+
+// Bit p of {hi, lo} set <=> byte p of the block is '\n' -- for any bytes (vkl::newline_mask64 wants ASCII).
+__device__ __forceinline__ void newline_mask64_any(const uint32_t d[16], uint32_t& lo, uint32_t& hi) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = vkl::udot4(nl_flags(d[2 * k + 1]), 0x80402010u, vkl::udot4(nl_flags(d[2 * k]), 0x08040201u, 0u));
+    lo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
+    hi = (v[4] >> 7) | (v[5] << 1) | (v[6] << 9) | (v[7] << 17);
+}
+
+// The anchors among the newlines of one lane's 64-byte block -- bit p of {mhi, mlo}: byte p is a newline; lph: phase of
+// the line the block begins in; blk: the block's sample offset -- stored behind the `nanch` the wavefront's segment
+// holds (cap: its room; `full` is raised instead of writing beyond it), and the block's share of the site count: the
+// positions of the sequence lines' ends minus the positions behind their anchors.  All lanes call it (`mine`: this
+// lane's block takes part); a round per newline of the fullest block.
+__device__ __forceinline__ void index_block(uint32_t mlo, uint32_t mhi, uint32_t lph, uint64_t blk, bool mine, uint32_t* seg, uint32_t cap,
+                                            uint32_t& nanch, bool& full, long long& acc) {
+    unsigned long long m = mine ? ((static_cast<unsigned long long>(mhi) << 32) | mlo) : 0ull;
+    const uint32_t ln = lane_now();
+    uint32_t t = 0;
+    while (__any(m != 0ull)) {   // newline by newline: three rounds for ordinary reads
+        const bool have = m != 0ull;
+        const uint32_t pos = have ? static_cast<uint32_t>(__builtin_ctzll(m)) : 0u;
+        m &= m - 1ull;
+        const uint32_t ph = (lph + t) & 3u;   // the line this newline ends
+        const bool anchor = have && ph == 0u;
+        if (have && ph == 1u) acc += static_cast<long long>(blk + pos);
+        if (anchor) acc -= static_cast<long long>(blk + pos) + 1ll;
+        const unsigned long long am = __ballot(anchor);
+        if (am != 0ull) {
+            const uint32_t na = static_cast<uint32_t>(__builtin_popcountll(am));
+            if (nanch + na > cap) full = true;
+            else if (anchor) seg[nanch + static_cast<uint32_t>(__builtin_popcountll(am & ((1ull << ln) - 1ull)))] = static_cast<uint32_t>(blk + pos);
+            if (!full) nanch += na;
+        }
+        ++t;
+    }
+}
+
 // ---- K <= 7, sequence-only heavy stage ("dense" kernel) ---------------------------------------
 // Same ranges, pieces, loads and histogram as vk_count_kernel; what changes is what a piece costs.
 // The LINE pass (vkl::newline_mask64 / seq_span, ~130 vector instructions per piece, no transposes)
@@ -894,27 +958,29 @@ __device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t o
     }
 }
 
-// This lane's number, recomputed where it is needed (two v_mbcnt): the dense kernel's piece loop holds no
-// per-lane value across iterations besides the prefetched bytes -- what lives across the call of the
-// general path would otherwise sit in scratch and come back with a vmcnt(0) wait at every use.
-__device__ __forceinline__ uint32_t lane_now() {
-    uint32_t l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-}
-
 // The general path of one piece for the dense kernel: exactly vk_count_kernel's piece (all 64 bytes of
 // every lane classified, any number of newlines, bytes >= 0x80, the low-complexity window loop); the
 // mask tables of the rare tiers are worked out on the spot (no LDS left for them).
 struct GeneralState {
     uint32_t ctx_c, ctx_bad, pph, hot, tick;   // in / out (wave-uniform)
+    uint32_t nanch, full, sites;               // INDEX: anchors in the wave's segment (in / out), segment full (out), this lane's sequence bytes (out)
 };
 
+
+
 // (bytes and state travel in registers: through a struct in memory every call cost a round trip to scratch)
-template <int K>
+// `packed`: bit 0 first piece of the range, bit 1 it starts with a pre-block, bits 2-3 the line phase at the range's start,
+// bits 4.. the bytes of the piece that lie inside the range (the last piece's tail is zero fill, not text).
+// INDEX: iseg / icap = the wave's segment of the anchor list and its room, iblk = sample offset of the piece's first byte.
+// (Scalars only, thirty-two dwords of them: everything travels in registers.  A small struct passed by value went
+// through the caller's stack frame, and hipcc 7.2 let its slot share bytes with a value spilled around the same call --
+// the site counts of the read index came back with whatever the slot held.)
+template <int K, bool INDEX>
 __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 q1, uint4 q2, uint4 q3, GeneralState st,
-                                                                uint32_t flags, uint32_t ph0, int lane, uint32_t* hist,
-                                                                uint32_t hist_base) {
+                                                                uint32_t packed, uint32_t* hist, uint32_t hist_base,
+                                                                uint32_t* iseg, uint32_t icap, uint32_t iblk) {
+    const uint32_t flags = packed & 3u, ph0 = (packed >> 2) & 3u, ivalid = packed >> 4;
+    const int lane = static_cast<int>(lane_now());
     const uint32_t d[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
     const bool first = (flags & 1u) != 0u, has_pre = (flags & 2u) != 0u;  // first piece of the range; it starts with a pre-block
     uint32_t pph = st.pph;
@@ -939,6 +1005,32 @@ __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 
     st.ctx_c = lane_bcast(lb.C[3], 63);
     vkl::ok_mask<K>(badh, bad, ok);
     if (first && lane == 0 && has_pre) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+    if constexpr (INDEX) {   // the piece's anchors and sequence bytes (the pre-block is the wave before's)
+        const bool mine = !(first && lane == 0 && has_pre);
+        uint32_t mlo, mhi;
+        {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = vkl::udot4(nl_flags(d[2 * j + 1]), 0x80402010u, vkl::udot4(nl_flags(d[2 * j]), 0x08040201u, 0u));
+            mlo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
+            mhi = (v[4] >> 7) | (v[5] << 1) | (v[6] << 9) | (v[7] << 17);
+        }
+        bool full = false;
+        long long unused = 0;
+        uint32_t nanch = st.nanch;
+        index_block(mlo, mhi, lph, static_cast<uint64_t>(iblk) + 64u * static_cast<uint32_t>(lane), mine, iseg, icap, nanch, full, unused);
+        st.nanch = nanch;
+        st.full = full ? 1u : 0u;
+        uint32_t sites = 0;
+        const int vb = static_cast<int>(ivalid) - 64 * lane;     // bytes of this lane's block inside the range
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int vg = vb - 16 * g;
+            const uint32_t inside = vg >= 16 ? 0xFFFFFFFFu : (vg <= 0 ? 0u : ((1u << (2 * vg)) - 1u));
+            sites += vkl::popc(seq.w[g] & ~lb.NL[g] & inside & 0x55555555u);
+        }
+        st.sites = mine ? sites : 0u;
+    }
     uint32_t pa;
     unsigned long long pm;
     uint32_t still = 0;
@@ -974,11 +1066,12 @@ constexpr uint32_t kSetAsideBatch = 21;   // entries a wavefront counts at a tim
 // atomics -- a few thousand per sample).  The deferred count as a function of the count kernel itself, called or
 // inlined behind its piece loop, made the K = 5 build lose the counts of that loop (gfx950, ROCm 7.2; not understood:
 // the same source was exact for K = 6, 7 and for K = 5 as soon as the function's adds were compiled out).
-template <int K>
+// INDEX: the listed lanes' anchors and sequence bytes are added to the read index (vk_count_dense_kernel<K, true>).
+template <int K, bool INDEX>
 __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
                                                         const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
                                                         uint32_t* __restrict__ hist_out, const uint32_t* __restrict__ aside,
-                                                        uint32_t aside_cap, const uint32_t* __restrict__ aside_n) {
+                                                        uint32_t aside_cap, const uint32_t* __restrict__ aside_n, IndexParams ip) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr uint32_t NCODE = 1u << (2 * K);
     const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);   // wave of the count launch: unit * kWaves + wave
@@ -997,6 +1090,14 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
     uint32_t* hist = hist_out + static_cast<uint64_t>(smp) * NCODE;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t ent = lane / 3u, j = lane - 3u * ent;
+    uint32_t* iseg = nullptr;
+    uint32_t icap = 0, nanch = 0, isites = 0;
+    bool ifull = false;
+    if constexpr (INDEX) {
+        iseg = ip.anchors + index_segment(ip, smp, wr.w0, part, static_cast<int>(wave));
+        icap = static_cast<uint32_t>(index_segment_cap(wr.w1 - wr.w0));
+        nanch = ip.count[gw];
+    }
     for (uint32_t at = 0; at < naside; at += kSetAsideBatch) {
         const uint32_t n = naside - at < kSetAsideBatch ? naside - at : kSetAsideBatch;
         const bool live = ent < n;
@@ -1023,15 +1124,43 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
         if (j == 1u && (w & 4u) != 0u) ok[0] &= ~kBack;
         if (j == 2u) { ok[0] &= kBack; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
         vkl::windows<K>(ch, lb.C, ok, [&](uint32_t field4) { atomicAdd(&hist[pair_reverse(field4 >> 2, K)], 1u); }, [] {});
+        if constexpr (INDEX) {   // the lane's own block (j = 1): its anchors, its sequence bytes
+            const bool mine = live && j == 1u;
+            uint32_t mlo, mhi;
+            {
+                uint32_t v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = vkl::udot4(nl_flags(d[2 * jj + 1]), 0x80402010u, vkl::udot4(nl_flags(d[2 * jj]), 0x08040201u, 0u));
+                mlo = (v[0] >> 7) | (v[1] << 1) | (v[2] << 9) | (v[3] << 17);
+                mhi = (v[4] >> 7) | (v[5] << 1) | (v[6] << 9) | (v[7] << 17);
+            }
+            long long unused = 0;
+            index_block(mlo, mhi, lph, o0 + static_cast<uint64_t>(off), mine, iseg, icap, nanch, ifull, unused);
+            if (mine) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) isites += vkl::popc(seq.w[g] & ~lb.NL[g] & 0x55555555u);
+            }
+        }
+    }
+    if constexpr (INDEX) {
+        const uint32_t tot = lane_bcast(wave_inclusive_sum(isites), 63);
+        if (lane == 0u) {
+            ip.count[gw] = nanch;
+            if (tot != 0u) atomicAdd(&ip.sites[smp], static_cast<unsigned long long>(tot));
+            if (ifull) atomicOr(&ip.overflow[smp], 1u);
+        }
     }
 }
 
-template <int K>
+// INDEX: the launch also fills the read index of its samples (vk_ladder.h) -- every read's anchor, the bytes of all
+// sequence lines -- so that a ladder of subsamples needs no pass of its own for it: an anchor falls out of the line pass
+// (seq_span's s_raw), the sequence bytes out of the heavy stage's masks; the general path and vk_aside_kernel add theirs.
+template <int K, bool INDEX>
 __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, int atomic_flush,
-    uint32_t* __restrict__ aside, uint32_t aside_cap, uint32_t* __restrict__ aside_n) {   // aside[grid * kWaves][aside_cap]: the waves' lists of lanes set aside; aside_n[grid * kWaves]: their lengths
+    uint32_t* __restrict__ aside, uint32_t aside_cap, uint32_t* __restrict__ aside_n, IndexParams ip) {   // aside[grid * kWaves][aside_cap]: the waves' lists of lanes set aside; aside_n[grid * kWaves]: their lengths
     constexpr uint32_t NCODE = 1u << (2 * K);
     static_assert(NCODE <= kMaxBins, "LDS histogram too large");
     __shared__ uint32_t hist[NCODE];       // raw-field order, as in vk_count_kernel
@@ -1048,7 +1177,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     __syncthreads();
 
     const WaveRange wr = wave_range(lens[smp], parts, part, wave);
-    uint32_t ph_start = 0, ph_end = 0, general_pieces = 0, aside_count = 0;
+    uint32_t ph_start = 0, ph_end = 0, general_pieces = 0, aside_count = 0, anchors = 0;
     if (!wr.empty) {
         const uint32_t hist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
             (__attribute__((address_space(3))) uint32_t*)hist));
@@ -1099,6 +1228,11 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         uint32_t* const alist = aside + (static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)) * aside_cap;
         uint32_t naside = 0;    // entries in alist
         bool aside63 = false;   // lane 63 of the piece before was set aside
+        // INDEX: the wave's segment of the sample's anchor list
+        uint32_t* const iseg = INDEX ? ip.anchors + uniform64(index_segment(ip, smp, w0, part, wave)) : nullptr;
+        const uint32_t icap = INDEX ? static_cast<uint32_t>(index_segment_cap(w1 - w0)) : 0u;
+        uint32_t nanch = 0, nsite = 0;   // anchors stored; this lane's sequence bytes so far
+        bool ifull = false;
 
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
@@ -1109,6 +1243,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
 #endif
             uint32_t C, IV, SEQ;
             vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
+            if constexpr (INDEX) nsite += vkl::popc(SEQ & 0x55555555u);
             const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
             const uint32_t badh = wave_prev_lane(bad, ctx_bad);
             const uint32_t ch = wave_prev_lane(C, ctx_c);
@@ -1164,7 +1299,8 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 const uint32_t incl = wave_inclusive_sum(c);
                 total = lane_bcast(incl, 63);
                 const uint32_t lph = (pph + incl - c) & 3u;
-                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e);
+                uint32_t s_raw;
+                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e, s_raw);
                 const unsigned long long am = __ballot(!plain);
                 if (am != 0ull) {   // rare: lanes set aside (see above), or too many of them
                     const uint32_t na = static_cast<uint32_t>(__builtin_popcountll(am));
@@ -1188,6 +1324,20 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                     }
                 }
                 if (fast) aside63 = (am >> 63) != 0ull;
+                if constexpr (INDEX) {
+                    // a plain lane holds one anchor at most: the newline its sequence line begins behind (a lane set aside
+                    // leaves its anchors to vk_aside_kernel, a piece that goes the general way after all to general_piece)
+                    const bool has = fast && plain && s_raw >= 1u && s_raw <= 64u;
+                    const unsigned long long hm = __ballot(has);
+                    if (hm != 0ull) {
+                        const uint32_t nh = static_cast<uint32_t>(__builtin_popcountll(hm));
+                        const uint32_t ln = lane_now();
+                        if (nanch + nh > icap) ifull = true;
+                        else if (has) iseg[nanch + static_cast<uint32_t>(__builtin_popcountll(hm & ((1ull << ln) - 1ull)))] =
+                                 static_cast<uint32_t>(o0) + it * static_cast<uint32_t>(kPiece) + 64u * ln + s_raw - 1u;
+                        if (!ifull) nanch += nh;
+                    }
+                }
             }
             if (!fast) aside63 = false;
             if (!fast) {
@@ -1197,8 +1347,15 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 ++ngeneral;
                 GeneralState gs;
                 gs.ctx_c = ctx_c; gs.ctx_bad = ctx_bad; gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
-                gs = general_piece<K>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u), ph0,
-                                      static_cast<int>(lane_now()), hist, hist_base);
+                gs.nanch = nanch; gs.full = 0u; gs.sites = 0u;
+                const uint32_t valid = (it + 1 == npieces && tail_bytes != 0u) ? tail_bytes : static_cast<uint32_t>(kPiece);
+                gs = general_piece<K, INDEX>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u) | (ph0 << 2) | (valid << 4),
+                                             hist, hist_base, iseg, icap, static_cast<uint32_t>(o0) + it * static_cast<uint32_t>(kPiece));
+                if constexpr (INDEX) {
+                    nanch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.nanch)));
+                    if (__builtin_amdgcn_readfirstlane(static_cast<int>(gs.full)) != 0) ifull = true;
+                    nsite += gs.sites;
+                }
                 ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.ctx_c)));
                 ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.ctx_bad)));
                 pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.pph)));
@@ -1261,6 +1418,14 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         ph_end = pph & 3u;
         general_pieces = ngeneral < 0xFFFFFFu ? ngeneral : 0xFFFFFFu;
         aside_count = naside;
+        if constexpr (INDEX) {
+            anchors = nanch;
+            const uint32_t tot = lane_bcast(wave_inclusive_sum(nsite), 63);
+            if (lane == 0) {
+                if (tot != 0u) atomicAdd(&ip.sites[smp], static_cast<unsigned long long>(tot));
+                if (ifull || len >= (1ull << 32)) atomicOr(&ip.overflow[smp], 1u);
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
 #ifdef VK_STAMPS
         if (lane == 0 && (blockIdx.x & 63u) == 0u) {  // [5] wait for the piece's bytes, [6] whole iterations, [7] pieces
@@ -1273,6 +1438,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     if (lane == 0) {
         wavephase[unit * kWaves + wave] = wr.empty ? 0x80u : (0x40u | ph_start | (ph_end << 2) | (general_pieces << 8));
         aside_n[unit * kWaves + wave] = aside_count;   // (vk_aside_kernel counts the listed lanes)
+        if constexpr (INDEX) ip.count[unit * kWaves + wave] = anchors;
     }
 
     __syncthreads();

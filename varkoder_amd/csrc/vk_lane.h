@@ -551,7 +551,9 @@ VKL_FN uint32_t first_bit64(uint32_t lo, uint32_t hi) {  // index of the lowest 
 // the end of that line (reads under 15 bases); a granule that holds two line ends in front of the start
 // (headers under 15 bytes).  The caller counts the windows of such a lane apart (vk_count.h, "lanes set
 // aside").
-VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e) {
+// s_raw: the stretch's start before clamping -- 1 .. 64 exactly when a sequence line begins behind a newline of this
+// block (that newline, at s_raw - 1, is its read's anchor), 0 when the block begins inside one, 65 when none begins.
+VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e, uint32_t& s_raw) {
     const uint32_t dn = (1u - lph) & 3u;  // line ends to pass before a sequence line starts
     const uint32_t p1 = first_bit64(lo, hi);
     const uint32_t lo1 = lo & (lo - 1u), hi1 = lo ? hi : (hi & (hi - 1u));
@@ -559,13 +561,19 @@ VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_
     // the candidates (-1, p1, p2, 64, 64) in consecutive bytes; a funnel shift by 8 dn picks (start - 1, end)
     const uint32_t cand = 0xFFu | (p1 << 8) | (p2 << 16) | (64u << 24);
     const uint32_t pr = alignbit(64u, cand, 8u * dn);
-    s = umin(((pr & 0xFFu) + 1u) & 0xFFu, 64u);
+    s_raw = ((pr & 0xFFu) + 1u) & 0xFFu;
+    s = umin(s_raw, 64u);
     e = (pr >> 8) & 0xFFu;
     const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64: s & 15 == 0)
     // A tagged granule's sequence bytes are those behind its FIRST newline: with dn = 2 the line end before the one
     // the stretch starts behind (p1) must lie in an earlier granule.
     const bool two = dn == 2u && (s & 15u) != 0u && (p1 >> 4) == (p2 >> 4);
     return c <= (dn >= 2u ? 2u : 3u) && !both && !two;
+}
+
+VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e) {
+    uint32_t s_raw;
+    return seq_span(lo, hi, c, lph, s, e, s_raw);
 }
 
 // The granules of a lane that go to the heavy stage: every granule with a position of line phase 1,
@@ -608,6 +616,34 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
     Cout = C;
     IVout = IV;
     SEQout = starts_inside ? ~((low << 2) | 3u) : low;
+}
+
+// The same for any bytes (no ASCII precondition), with the newline flags instead of a sequence mask: the subsample
+// walker (vk_ladder.h) knows where its read starts and only asks where it ends.
+VKL_FN void classify_granule_any(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout, uint32_t& NLout) {
+    constexpr uint32_t kLutLo = 0x41204020u, kLutHi = 0x42202053u;  // as in classify()
+    const uint32_t k7f = 0x7F7F7F7Fu;
+    const uint32_t p01l = perm(a1, a0, 0x05010400u), p01h = perm(a1, a0, 0x07030602u);
+    const uint32_t p23l = perm(a3, a2, 0x05010400u), p23h = perm(a3, a2, 0x07030602u);
+    const uint32_t T[4] = {perm(p23l, p01l, 0x05040100u), perm(p23l, p01l, 0x07060302u),
+                           perm(p23h, p01h, 0x05040100u), perm(p23h, p01h, 0x07060302u)};
+    uint32_t C = 0, IV = 0, NL = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = T[j];
+        const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
+        const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
+        C = j == 0 ? (x & 0x03030303u) : lshl_or(x & 0x03030303u, 2 * j, C);
+        const uint32_t nz = ((x & 0x7C7C7C7Cu) + k7f) | x;
+        const uint32_t eq = ~(xor_add_k(t & k7f, 0x0A0A0A0Au, k7f) | t);
+        IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+        NL = j == 0 ? ((eq >> 7) & 0x01010101u) : and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
+    }
+    Cout = C;
+    IVout = IV;
+    NLout = NL;
 }
 
 // OK of the 16 positions of one granule (even bits) from its BAD string and the one before it.

@@ -31,7 +31,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "vkimg.h"
@@ -39,6 +41,7 @@
 
 #include "vk_count.h"
 #include "vk_pack.h"
+#include "vk_ladder.h"
 #include "vk_image.h"
 #include "vk_inflate.h"
 #include "vk_aux.h"
@@ -63,6 +66,16 @@ struct vk_ctx {
     uint32_t desc_n = 0;
     uint32_t* d_wavephase = nullptr;
     size_t wavephase_cap = 0;
+    // read index of a batch (vk_read_index_device): anchors | sample bases | segment counts | sites | overflow flags
+    uint8_t* d_index = nullptr;
+    size_t index_cap = 0;
+    IndexParams ix{};
+    const void* ix_fastq = nullptr;
+    uint32_t ix_parts = 0;
+    std::map<std::pair<uint64_t, uint64_t>, uint32_t> ix_sample;   // (offset, length) -> sample of the index
+    std::vector<uint32_t> ix_status, ix_overflow;                  // per indexed sample (host copies)
+    uint32_t* d_walk = nullptr;   // per-pair arrays of a walker launch
+    size_t walk_cap = 0;
     uint32_t* d_aside = nullptr;  // k <= 7: the waves' lists of lanes set aside
     size_t aside_cap = 0;
     uint32_t* d_scratch = nullptr;
@@ -94,6 +107,7 @@ struct vk_ctx {
     size_t synth_offs_cap = 0;
     uint32_t* d_hist1 = nullptr;
     uint32_t* d_status1 = nullptr;
+    size_t status1_cap = 0;
     uint8_t* d_img1 = nullptr;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
@@ -173,7 +187,8 @@ uint32_t npad_of(uint32_t npix) {
 
 template <int K>
 int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
-                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub) {
+                 uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub,
+                 const IndexParams* index = nullptr) {
     const uint32_t grid = nsamples * parts;
     const int atomic_flush = parts > 1 ? 1 : 0;
     if (atomic_flush)
@@ -185,7 +200,7 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     if (sub)
         hipLaunchKernelGGL((vk_count_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, *sub);
-    else if (ctx->k1_classic)
+    else if (ctx->k1_classic && !index)
         hipLaunchKernelGGL((vk_count_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
     else {
@@ -200,12 +215,21 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_aside), &ctx->aside_cap, need);
         if (rc) return rc;
         uint32_t* const d_aside_n = ctx->d_aside + nwaves * cap;
-        hipLaunchKernelGGL((vk_count_dense_kernel<K>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
-                           static_cast<uint32_t>(cap), d_aside_n);
-        VK_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((vk_aside_kernel<K>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
-                           d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n);
+        if (index) {   // the count and the read index of the samples in one pass (vk_count_index_device)
+            hipLaunchKernelGGL((vk_count_dense_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
+                               static_cast<uint32_t>(cap), d_aside_n, *index);
+            VK_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL((vk_aside_kernel<K, true>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, *index);
+        } else {
+            hipLaunchKernelGGL((vk_count_dense_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
+                               static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
+            VK_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
+        }
     }
     VK_HIP(ctx, hipGetLastError());
     return VK_OK;
@@ -304,8 +328,8 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
             hipLaunchKernelGGL(vk_pack_kernel, dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs + s0,
                                d_lens + s0, n, parts, pk, wph0, ctx->d_aside, aside_cap, d_aside_n);
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K>), dim3((n * parts * kWaves + 3) / 4), dim3(256), 0, ctx->stream, d_fastq,
-                               d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n);
+            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3((n * parts * kWaves + 3) / 4), dim3(256), 0, ctx->stream, d_fastq,
+                               d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n, IndexParams{});
             VK_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL((vk_bucket_kernel<K, 2>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
                                d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, pk);
@@ -419,7 +443,7 @@ void vk_ctx_destroy(vk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 10; ++k)
         if (ctx->d_pix[k]) (void)hipFree(ctx->d_pix[k]);
-    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc, ctx->d_synth, ctx->d_synth_offs, ctx->d_aside};
+    void* ptrs[] = {ctx->d_desc, ctx->d_wavephase, ctx->d_scratch, ctx->d_spill, ctx->d_stage, ctx->d_hist1, ctx->d_status1, ctx->d_img1, ctx->d_sub, ctx->d_gzjobs, ctx->d_gzmeta, ctx->d_gzsym, ctx->d_gzwin, ctx->d_gzcrc, ctx->d_synth, ctx->d_synth_offs, ctx->d_aside, ctx->d_index, ctx->d_walk};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
@@ -520,6 +544,77 @@ int vk_set_mapping(vk_ctx* ctx, int k, const uint32_t* pix, uint32_t npix) {
     return VK_OK;
 }
 
+}  // extern "C"
+
+// Subsampled counts through the read index (vk_ladder.h): every (offset, length) of the call is a sample the context
+// holds an index of.  Returns VK_OK with *done = true when the walker ran.
+constexpr uint64_t kWalkMaxThresholdSpill = (1ull << 32) / 32;   // k = 8, 9: largest fraction of the reads (as a threshold) the walker takes
+
+template <int K>
+static void launch_walk(vk_ctx* ctx, const uint8_t* fq, const uint64_t* d_offs, const uint64_t* d_lens, uint32_t npairs,
+                        const WalkParams& wp, uint32_t* d_hist, int atomic_flush) {
+    hipLaunchKernelGGL((vk_walk_kernel<K>), dim3(npairs * wp.iparts), dim3(kCountThreads), 0, ctx->stream, fq, d_offs, d_lens, npairs,
+                       ctx->ix, wp, d_hist, atomic_flush);
+}
+
+static int count_walk(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths, uint32_t nsamples, int k,
+                      uint32_t* d_hist, uint32_t* d_status, const uint64_t* seeds, const uint64_t* thresholds, uint64_t* d_sites,
+                      bool* done) {
+    *done = false;
+    if (ctx->ix_fastq != d_fastq || ctx->ix_sample.empty() || getenv("VKIMG_NO_READ_INDEX")) return VK_OK;
+    std::vector<uint32_t> isample(nsamples), status(nsamples);
+    for (uint32_t i = 0; i < nsamples; ++i) {
+        // k = 8, 9: the walker counts into the subsample's row in HBM, one atomic per window (~28 G/s measured): it beats a
+        // streamed pass of the spill path only for subsamples of a few per cent of the reads
+        if (k > 7 && thresholds[i] > kWalkMaxThresholdSpill) return VK_OK;
+        const auto it = ctx->ix_sample.find(std::make_pair(offsets[i], lengths[i]));
+        if (it == ctx->ix_sample.end() || ctx->ix_overflow[it->second]) return VK_OK;   // not indexed: the streaming kernels
+        isample[i] = it->second;
+        status[i] = ctx->ix_status[it->second];
+    }
+    const uint32_t parts = ctx->ix_parts;
+    if (static_cast<uint64_t>(nsamples) * parts > (1u << 24)) return VK_OK;
+    // per-pair arrays: offsets | lengths | seeds | thresholds (u64 each) | isample (u32)
+    const size_t need = static_cast<size_t>(nsamples) * (4 * sizeof(uint64_t) + sizeof(uint32_t)) + 64;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_walk), &ctx->walk_cap, need);
+    if (rc) return rc;
+    uint64_t* d64 = reinterpret_cast<uint64_t*>(ctx->d_walk);
+    uint32_t* d_is = reinterpret_cast<uint32_t*>(d64 + 4ull * nsamples);
+    VK_HIP(ctx, hipMemcpyAsync(d64, offsets, nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d64 + nsamples, lengths, nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d64 + 2ull * nsamples, seeds, nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d64 + 3ull * nsamples, thresholds, nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d_is, isample.data(), nsamples * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(d_status, status.data(), nsamples * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the host vectors are temporaries)
+    if (d_sites) VK_HIP(ctx, hipMemsetAsync(d_sites, 0, 2ull * nsamples * sizeof(uint64_t), ctx->stream));
+    const int atomic_flush = (parts > 1 || k > 7) ? 1 : 0;
+    if (atomic_flush)
+        VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * (1ull << (2 * k)) * sizeof(uint32_t), ctx->stream));
+    WalkParams wp;
+    wp.isample = d_is;
+    wp.seeds = d64 + 2ull * nsamples;
+    wp.thresholds = d64 + 3ull * nsamples;
+    wp.sites = reinterpret_cast<unsigned long long*>(d_sites);
+    wp.iparts = parts;
+    const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
+    ctx->last_grid = nsamples * parts;
+    ctx->last_block = kCountThreads;
+    ctx->last_lds = (k <= 7 ? (1u << (2 * k)) * 4u : 4u) + kWaves * kWalkQueue * 4u;
+    switch (k) {
+        case 5: launch_walk<5>(ctx, fq, d64, d64 + nsamples, nsamples, wp, d_hist, atomic_flush); break;
+        case 6: launch_walk<6>(ctx, fq, d64, d64 + nsamples, nsamples, wp, d_hist, atomic_flush); break;
+        case 7: launch_walk<7>(ctx, fq, d64, d64 + nsamples, nsamples, wp, d_hist, atomic_flush); break;
+        case 8: launch_walk<8>(ctx, fq, d64, d64 + nsamples, nsamples, wp, d_hist, atomic_flush); break;
+        default: launch_walk<9>(ctx, fq, d64, d64 + nsamples, nsamples, wp, d_hist, atomic_flush); break;
+    }
+    VK_HIP(ctx, hipGetLastError());
+    *done = true;
+    return VK_OK;
+}
+
+extern "C" {
+
 static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths,
                       uint32_t nsamples, int k, uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status,
                       const uint64_t* seeds, const uint64_t* thresholds, uint64_t* d_sites) {
@@ -533,6 +628,11 @@ static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
         if (lengths[i] > maxlen) maxlen = lengths[i];
     }
     if ((reinterpret_cast<uintptr_t>(d_fastq) & 15u) != 0) return VK_EINVAL;
+    if (seeds) {   // subsamples of samples the context holds a read index of: the walker (vk_ladder.h)
+        bool done = false;
+        const int rcw = count_walk(ctx, d_fastq, offsets, lengths, nsamples, k, d_hist, d_status, seeds, thresholds, d_sites, &done);
+        if (rcw || done) return rcw;
+    }
     uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
     // a wavefront addresses its byte range through a 32-bit buffer descriptor (vk_count.h, wave_stream):
     // keep every range below 2 GiB, whatever the caller asked for
@@ -598,6 +698,141 @@ int vk_count_sampled_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* of
                       thresholds, d_sites);
 }
 
+}  // extern "C"
+
+namespace {
+
+// Workspace and descriptors of a read index over the samples of a call (vk_ladder.h): *ip describes it, *parts_out is the
+// split the index is laid out for.  The samples' descriptors are on the device (ctx->d_desc) on return.
+int index_prepare(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths, uint32_t nsamples,
+                  uint32_t parts_per_sample, IndexParams* ip, uint32_t* parts_out, uint64_t* maxlen_out) {
+    ctx->ix_fastq = nullptr;
+    ctx->ix_sample.clear();
+    if (!d_fastq || (reinterpret_cast<uintptr_t>(d_fastq) & 15u) != 0) return VK_EINVAL;
+    VK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t maxlen = 0;
+    for (uint32_t i = 0; i < nsamples; ++i) {
+        if ((offsets[i] & 15u) != 0) return VK_EINVAL;
+        if (lengths[i] > maxlen) maxlen = lengths[i];
+    }
+    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
+    while (maxlen / (static_cast<uint64_t>(parts) * kWaves) >= (1ull << 31)) parts *= 2;
+    if (static_cast<uint64_t>(nsamples) * parts > (1u << 24)) return VK_EINVAL;
+    const size_t nwaves = static_cast<size_t>(nsamples) * parts * kWaves;
+    // anchors: a sample's region holds one per 32 bytes of text, and eight per wavefront on top
+    std::vector<uint64_t> base(nsamples);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < nsamples; ++i) {
+        base[i] = total;
+        total += lengths[i] / 32 + 8ull * parts * kWaves + 16;
+    }
+    const size_t o_base = (total * sizeof(uint32_t) + 255) / 256 * 256, o_count = o_base + nsamples * sizeof(uint64_t),
+                 o_sites = (o_count + nwaves * sizeof(uint32_t) + 7) / 8 * 8, o_over = o_sites + nsamples * sizeof(uint64_t),
+                 bytes = o_over + nsamples * sizeof(uint32_t);
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_index), &ctx->index_cap, bytes + 256);
+    if (rc) return rc;
+    if (ctx->desc_cap < 2ull * nsamples * sizeof(uint64_t)) ctx->desc_n = 0;
+    rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_desc), &ctx->desc_cap, 2ull * nsamples * sizeof(uint64_t));
+    if (rc) return rc;
+    rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_wavephase), &ctx->wavephase_cap, nwaves * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = upload_desc(ctx, offsets, lengths, nsamples);
+    if (rc) return rc;
+    uint8_t* m = ctx->d_index;
+    ip->anchors = reinterpret_cast<uint32_t*>(m);
+    ip->base = reinterpret_cast<const uint64_t*>(m + o_base);
+    ip->count = reinterpret_cast<uint32_t*>(m + o_count);
+    ip->sites = reinterpret_cast<unsigned long long*>(m + o_sites);
+    ip->overflow = reinterpret_cast<uint32_t*>(m + o_over);
+    VK_HIP(ctx, hipMemcpyAsync(m + o_base, base.data(), nsamples * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (base is a temporary)
+    VK_HIP(ctx, hipMemsetAsync(m + o_sites, 0, bytes - o_sites, ctx->stream));
+    *parts_out = parts;
+    *maxlen_out = maxlen;
+    return VK_OK;
+}
+
+// The index is filled and d_status holds the samples' status words: bring sites, overflow flags and status to the host and
+// remember which samples the index covers.
+int index_finish(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths, uint32_t nsamples,
+                 const IndexParams& ip, uint32_t parts, const uint32_t* d_status, uint64_t* sites, uint32_t* status) {
+    ctx->ix_status.assign(nsamples, 0u);
+    ctx->ix_overflow.assign(nsamples, 0u);
+    VK_HIP(ctx, hipMemcpyAsync(sites, ip.sites, nsamples * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(ctx->ix_overflow.data(), ip.overflow, nsamples * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipMemcpyAsync(ctx->ix_status.data(), d_status, nsamples * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < nsamples; ++i) {
+        status[i] = ctx->ix_status[i];
+        ctx->ix_sample[std::make_pair(offsets[i], lengths[i])] = i;
+    }
+    ctx->ix = ip;
+    ctx->ix_fastq = d_fastq;
+    ctx->ix_parts = parts;
+    return VK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_read_index_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths, uint32_t nsamples,
+                         uint32_t parts_per_sample, uint64_t* sites, uint32_t* status) {
+    if (!ctx || !offsets || !lengths || !sites || !status) return VK_EINVAL;
+    ctx->ix_fastq = nullptr;
+    ctx->ix_sample.clear();
+    if (nsamples == 0) return VK_OK;
+    IndexParams ip;
+    uint32_t parts = 0;
+    uint64_t maxlen = 0;
+    int rc = index_prepare(ctx, d_fastq, offsets, lengths, nsamples, parts_per_sample, &ip, &parts, &maxlen);
+    if (rc) return rc;
+    rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_status1), &ctx->status1_cap, nsamples * sizeof(uint32_t) + 64);
+    if (rc) return rc;
+    const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
+    hipLaunchKernelGGL(vk_index_kernel, dim3(nsamples * parts), dim3(kCountThreads), 0, ctx->stream, fq, ctx->d_desc, ctx->d_desc + nsamples,
+                       nsamples, parts, ip, ctx->d_wavephase);
+    VK_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, ctx->d_desc, ctx->d_desc + nsamples,
+                       nsamples, parts, ctx->d_wavephase, ctx->d_status1);
+    VK_HIP(ctx, hipGetLastError());
+    return index_finish(ctx, d_fastq, offsets, lengths, nsamples, ip, parts, ctx->d_status1, sites, status);
+}
+
+int vk_count_index_device(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, const uint64_t* lengths, uint32_t nsamples, int k,
+                          uint32_t parts_per_sample, uint32_t* d_hist, uint32_t* d_status, uint64_t* sites, uint32_t* status) {
+    if (!ctx || !offsets || !lengths || !d_hist || !d_status || !sites || !status || k < 5 || k > 9) return VK_EINVAL;
+    ctx->ix_fastq = nullptr;
+    ctx->ix_sample.clear();
+    if (nsamples == 0) return VK_OK;
+    if (k > 7) {   // the spill path has no index mode: the index in a pass of its own, then the count
+        int rc = vk_read_index_device(ctx, d_fastq, offsets, lengths, nsamples, parts_per_sample, sites, status);
+        if (rc) return rc;
+        return vk_count_device(ctx, d_fastq, offsets, lengths, nsamples, k, parts_per_sample, d_hist, d_status);
+    }
+    IndexParams ip;
+    uint32_t parts = 0;
+    uint64_t maxlen = 0;
+    int rc = index_prepare(ctx, d_fastq, offsets, lengths, nsamples, parts_per_sample, &ip, &parts, &maxlen);
+    if (rc) return rc;
+    const uint8_t* fq = static_cast<const uint8_t*>(d_fastq);
+    uint64_t* d_offs = ctx->d_desc;
+    uint64_t* d_lens = ctx->d_desc + nsamples;
+    switch (k) {
+        case 5: rc = launch_count<5>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, nullptr, &ip); break;
+        case 6: rc = launch_count<6>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, nullptr, &ip); break;
+        default: rc = launch_count<7>(ctx, fq, d_offs, d_lens, nsamples, parts, maxlen, d_hist, nullptr, &ip); break;
+    }
+    if (rc) return rc;
+    ctx->last_waves = static_cast<uint64_t>(nsamples) * parts * kWaves;
+    ctx->last_bytes = 0;
+    for (uint32_t i = 0; i < nsamples; ++i) ctx->last_bytes += lengths[i];
+    hipLaunchKernelGGL(vk_check_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, ctx->stream, fq, d_offs, d_lens,
+                       nsamples, parts, ctx->d_wavephase, d_status);
+    VK_HIP(ctx, hipGetLastError());
+    return index_finish(ctx, d_fastq, offsets, lengths, nsamples, ip, parts, d_status, sites, status);
+}
+
 int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int k, uint8_t* d_img) {
     if (!ctx || !d_hist || !d_img || k < 5 || k > 9) return VK_EINVAL;
     if (!ctx->d_pix[k]) return VK_ENOMAP;
@@ -641,7 +876,10 @@ int vk_count_host(vk_ctx* ctx, const uint8_t* fastq, size_t nbytes, int k, uint3
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_stage), &ctx->stage_cap, nbytes + 64);
     if (rc) return rc;
     if (!ctx->d_hist1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_hist1), (1u << 18) * sizeof(uint32_t)));
-    if (!ctx->d_status1) VK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_status1), 64));
+    {
+        const int rcs = ensure(ctx, reinterpret_cast<void**>(&ctx->d_status1), &ctx->status1_cap, 64);
+        if (rcs) return rcs;
+    }
     if (nbytes)
         VK_HIP(ctx, hipMemcpyAsync(ctx->d_stage, fastq, nbytes, hipMemcpyHostToDevice, ctx->stream));
     uint64_t off = 0, len = nbytes;

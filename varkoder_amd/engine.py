@@ -534,6 +534,38 @@ class ImageEngine:
         _capi.check(self.ctx, st, "vk_count_sampled_device")
         return hist, status, sites
 
+    def read_index(self, fastq, offsets, lengths, parts=0):
+        """The read index of a batch (vk_read_index_device): (nsites uint64[n], status uint32[n]) on the host; the
+        context keeps the index, and count_sampled calls on these samples walk the reads they take."""
+        offs, lens = self._desc(offsets, lengths)
+        n = len(offs)
+        sites = np.zeros(n, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.uint32)
+        u64p = C.POINTER(C.c_uint64)
+        st = self.L.vk_read_index_device(self.ctx, self._ptr(fastq), offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p), n, parts,
+                                         sites.ctypes.data_as(u64p), status.ctypes.data_as(C.POINTER(C.c_uint32)))
+        _capi.check(self.ctx, st, "vk_read_index_device")
+        return sites, status
+
+    def count_index(self, fastq, offsets, lengths, parts=0, hist=None, status=None):
+        """count() and read_index() in one pass over the text (vk_count_index_device):
+        (hist [n, 4^k] on the device, nsites uint64[n], status uint32[n] on the host)."""
+        torch = _torch()
+        offs, lens = self._desc(offsets, lengths)
+        n = len(offs)
+        if hist is None:
+            hist = torch.empty((n, self.ncode), dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        sites = np.zeros(n, dtype=np.uint64)
+        st_h = np.zeros(n, dtype=np.uint32)
+        u64p = C.POINTER(C.c_uint64)
+        st = self.L.vk_count_index_device(self.ctx, self._ptr(fastq), offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p), n, self.k,
+                                          parts, self._ptr(hist), self._ptr(status), sites.ctypes.data_as(u64p),
+                                          st_h.ctypes.data_as(C.POINTER(C.c_uint32)))
+        _capi.check(self.ctx, st, "vk_count_index_device")
+        return hist, sites, st_h
+
     def images(self, hist, img=None):
         """K2: uint8 images [n, side, side] from histograms [n, 4^k]."""
         torch = _torch()

@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-config4", action="store_true", help="skip the k=9 side leg (N=1 only)")
     ap.add_argument("--config4-samples", type=int, default=100)
     ap.add_argument("--config4-steps", type=int, default=5)
+    ap.add_argument("--no-ladder", action="store_true", help="skip the subsample-ladder leg (N=1 only)")
+    ap.add_argument("--ladder-samples", type=int, default=32)
     ap.add_argument("--no-realistic", action="store_true", help="skip the fastp-shaped read-length leg (N=1 only)")
     ap.add_argument("--realistic-pool", type=int, default=256)
     ap.add_argument("--realistic-steps", type=int, default=3)
@@ -503,6 +505,37 @@ def realistic(args, device_index):
     return out
 
 
+def ladder(args, device_index):
+    """The subsample ladder of step C on the GPU (split_fastq's 1-2-5 ladder, commands/image.py:682-695, every step a
+    Bernoulli subsample of the reads with its own seed): `--ladder-samples` samples of the main workload's shape, all steps
+    of all samples -- read index + full count in one pass, then ONE walker launch over every (sample, step) pair
+    (subsample.ladder_counts).  Wall time of the whole call, host logic included; the median of three."""
+    import torch
+    from varkoder_amd.engine import ImageEngine
+    from varkoder_amd.subsample import ladder_counts
+    eng = ImageEngine(k=args.k, mapping=args.mapping, device=device_index)
+    n = args.ladder_samples
+    buf, offs, lens = eng.synth(5000, n, args.reads, args.readlen, dist=args.dist)
+    times, steps = [], 0
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = ladder_counts(eng, buf, offs, lens, seed=5, min_bp=50000, max_bp=None)
+        torch.cuda.synchronize()
+        if rep:
+            times.append(time.perf_counter() - t0)
+        steps = sum(len(r["steps"]) for r in recs)
+        bad = sum(1 for r in recs if r["error"])
+    eng.close()
+    del buf
+    torch.cuda.empty_cache()
+    ms = sorted(times)[len(times) // 2] * 1e3
+    return {"samples": n, "steps": steps, "ms": ms, "ms_per_sample_ladder": ms / n, "passes_ms": [t * 1e3 for t in times],
+            "failed_samples": bad, "bases_of_one_full_pass": n * args.reads * args.readlen,
+            "note": "k=%d; every step of every sample: one pass for the read index + the full count, one walker launch for the "
+                    "rest (vk_count_index_device, vk_walk_kernel); round 3 streamed the text once per step (38.2 ms for 32 x 12)" % args.k}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -746,6 +779,11 @@ def main():
                 out["realistic"] = realistic(args, local_rank)
             except Exception as e:  # a side measurement: never lose the bench line over it
                 out["realistic"] = {"error": repr(e)}
+        if world == 1 and not args.no_ladder and args.k <= 7:
+            try:
+                out["ladder"] = ladder(args, local_rank)
+            except Exception as e:  # a side measurement: never lose the bench line over it
+                out["ladder"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e:
             try:
                 out["end_to_end"] = end_to_end(eng, args)

@@ -7,9 +7,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-e2e --no-config4"
+BENCH="python3 bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
-BENCHS="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4"
+BENCHS="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCHS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCHS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq1 -o pmc -- $BENCHS > $OUT/bench_sq1.json 2> $OUT/sq1.err

@@ -236,7 +236,7 @@ def test_bench_script_runs_end_to_end(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
                           "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5", "--e2e-files", "6",
-                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2", "--realistic-pool", "8", "--realistic-steps", "2"],
+                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2", "--realistic-pool", "8", "--realistic-steps", "2", "--ladder-samples", "3"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -270,6 +270,7 @@ def test_bench_script_runs_end_to_end(tmp_path):
     for leg in ("dense", "classic"):
         assert rl[leg]["bad_status_samples"] == 0 and rl[leg]["count_ms"] > 0
     assert 0 < rl["dense"]["general_piece_fraction"] <= 1 and rl["dense"]["pieces"] > 0
+    assert d["ladder"]["samples"] == 3 and d["ladder"]["steps"] >= 3 and d["ladder"]["ms"] > 0 and d["ladder"]["failed_samples"] == 0
 
 
 def test_bench_gpus_flag_starts_the_ranks_itself():

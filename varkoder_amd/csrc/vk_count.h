@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         uint32_t ngeneral = 0;  // pieces that took the general path (reported in the wave's phase word, bits 8..31)
         uint32_t* const alist = aside + (static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)) * aside_cap;
         uint32_t naside = 0;    // entries in alist
-        bool aside63 = false;   // lane 63 of the piece before was set aside
+        uint32_t aside63 = 0;   // lane 63 of the piece before was set aside (wave-uniform)
         // INDEX: the wave's segment of the sample's anchor list
         uint32_t* const iseg = INDEX ? ip.anchors + uniform64(index_segment(ip, smp, w0, part, wave)) : nullptr;
         const uint32_t icap = INDEX ? static_cast<uint32_t>(index_segment_cap(w1 - w0)) : 0u;
@@ -1313,17 +1313,17 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                     } else {
                         if (!plain) {
                             const uint32_t ln = lane_now();
-                            const bool before = ln == 0u ? aside63 : ((am >> (ln - 1u)) & 1ull) != 0ull;
-                            alist[naside + static_cast<uint32_t>(__builtin_popcountll(am & ((1ull << ln) - 1ull)))] =
-                                ((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph;
+                            const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));   // lanes set aside below this one
+                            const bool before = ln == 0u ? aside63 != 0u : ((am >> (ln - 1u)) & 1ull) != 0ull;
+                            alist[naside + below] = ((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph;
                             r0 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);   // the separator
                             s = 0u;
                             e = 15u;
                         }
-                        naside += na;
+                        naside = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(naside + na)));   // (kept in a scalar register)
                     }
                 }
-                if (fast) aside63 = (am >> 63) != 0ull;
+                aside63 = fast ? static_cast<uint32_t>(am >> 63) : 0u;   // (scalar: am is a ballot, fast wave-uniform)
                 if constexpr (INDEX) {
                     // a plain lane holds one anchor at most: the newline its sequence line begins behind (a lane set aside
                     // leaves its anchors to vk_aside_kernel, a piece that goes the general way after all to general_piece)
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                     }
                 }
             }
-            if (!fast) aside63 = false;
+            if (!fast) aside63 = 0u;
             if (!fast) {
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
                 // classified at once -- would spill the fast path's loop invariants) ----

@@ -561,7 +561,7 @@ VKL_FN bool seq_span(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_
     // the candidates (-1, p1, p2, 64, 64) in consecutive bytes; a funnel shift by 8 dn picks (start - 1, end)
     const uint32_t cand = 0xFFu | (p1 << 8) | (p2 << 16) | (64u << 24);
     const uint32_t pr = alignbit(64u, cand, 8u * dn);
-    s_raw = ((pr & 0xFFu) + 1u) & 0xFFu;
+    s_raw = (pr + 1u) & 0xFFu;
     s = umin(s_raw, 64u);
     e = (pr >> 8) & 0xFFu;
     const bool both = (s >> 4) == (e >> 4) && (s & 15u) != 0u;  // (s = 64: s & 15 == 0)

@@ -1061,24 +1061,39 @@ __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 
 constexpr uint32_t kSetAside = 6;         // lanes of one piece that may be set aside
 constexpr uint32_t kSetAsideBatch = 21;   // entries a wavefront counts at a time (three lanes each)
 
-// One wavefront per wave of the count launch that left a list: vk_aside_kernel<K><<<grid * kWaves / 4, 256>>>, behind
-// the count kernel in the stream (its histogram rows are stored by then; the windows found here are added with global
-// atomics -- a few thousand per sample).  The deferred count as a function of the count kernel itself, called or
-// inlined behind its piece loop, made the K = 5 build lose the counts of that loop (gfx950, ROCm 7.2; not understood:
-// the same source was exact for K = 6, 7 and for K = 5 as soon as the function's adds were compiled out).
+// vk_aside_kernel<K><<<count launch's grid, 1024>>>, behind the count kernel in the stream (its histogram rows are stored
+// by then): a workgroup per workgroup of the count launch, a wavefront per list.  k <= 7: the windows found go into a
+// histogram in LDS (raw-field order, the count kernels' window blocks) that is added to the sample's row at the end --
+// with one global atomic per window the kernel took 3.6 ms beside a 77 ms count of fastp-shaped reads (780 M atomics);
+// k = 8, 9 (the packed route): one atomic per window.  The deferred count as a function of the count kernel itself,
+// called or inlined behind its piece loop, made the K = 5 build lose the counts of that loop (gfx950, ROCm 7.2; not
+// understood: the same source was exact for K = 6, 7 and for K = 5 as soon as the function's adds were compiled out).
 // INDEX: the listed lanes' anchors and sequence bytes are added to the read index (vk_count_dense_kernel<K, true>).
 template <int K, bool INDEX>
-__global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
-                                                        const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
-                                                        uint32_t* __restrict__ hist_out, const uint32_t* __restrict__ aside,
-                                                        uint32_t aside_cap, const uint32_t* __restrict__ aside_n, IndexParams ip) {
+__global__ __launch_bounds__(kCountThreads, 8) void vk_aside_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
+                                                                     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
+                                                                     uint32_t* __restrict__ hist_out, const uint32_t* __restrict__ aside,
+                                                                     uint32_t aside_cap, const uint32_t* __restrict__ aside_n, IndexParams ip) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr uint32_t NCODE = 1u << (2 * K);
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);   // wave of the count launch: unit * kWaves + wave
-    if (gw >= nsamples * parts * kWaves) return;
+    constexpr bool LDSH = NCODE <= kMaxBins;
+    __shared__ uint32_t lhist[LDSH ? NCODE : 1];
+    __shared__ uint32_t any_list;
+    const uint32_t unit = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6)));
+    const uint32_t gw = unit * kWaves + wave;   // wave of the count launch
     const uint32_t naside = aside_n[gw];
-    if (naside == 0u) return;
-    const uint32_t unit = gw / kWaves, wave = gw % kWaves;
+    if (tid == 0) any_list = 0u;
+    __syncthreads();
+    if (naside != 0u && (tid & 63u) == 0u) any_list = 1u;
+    __syncthreads();
+    if (any_list == 0u) return;                 // (uniform for the workgroup: most workgroups of a launch on ordinary reads)
+    if constexpr (LDSH) {
+        for (uint32_t i = tid; i < NCODE; i += kCountThreads) lhist[i] = 0u;
+        __syncthreads();
+    }
+    const uint32_t lhist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)lhist));
     const uint32_t smp = unit / parts, part = unit % parts;
     const WaveRange wr = wave_range(lens[smp], parts, part, static_cast<int>(wave));
     const uint8_t* sbase = fastq + offs[smp];
@@ -1088,7 +1103,7 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
         const_cast<uint8_t*>(sbase + o0), 0, static_cast<int>((span + 15) & ~15ull), 0x00020000);
     const uint32_t* list = aside + static_cast<uint64_t>(gw) * aside_cap;
     uint32_t* hist = hist_out + static_cast<uint64_t>(smp) * NCODE;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = tid & 63u;
     const uint32_t ent = lane / 3u, j = lane - 3u * ent;
     uint32_t* iseg = nullptr;
     uint32_t icap = 0, nanch = 0, isites = 0;
@@ -1113,7 +1128,10 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
         const uint32_t c = vkl::classify<false>(d, lb);
         const uint32_t cprev = wave_prev_lane(c, 0u);
         const uint32_t lph = ((w & 3u) + (j == 0u ? 0u - c : (j == 2u ? cprev : 0u))) & 3u;
-        const vkl::Mask128 seq = vkl::seq_mask_general(lb.NL, lph);
+        vkl::Mask128 seq;
+        uint32_t s_raw = 0;
+        if (__any(c > 4u)) seq = vkl::seq_mask_general(lb.NL, lph);   // (position by position: slow, and rarely needed)
+        else seq = vkl::seq_mask_fast4(lb.NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
         uint32_t bad[4], ok[4];
         vkl::bad_mask(lb, seq, bad);
         const uint32_t badh = wave_prev_lane(bad[3], 0x55555555u);
@@ -1123,7 +1141,13 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
         if (!live || j == 0u) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
         if (j == 1u && (w & 4u) != 0u) ok[0] &= ~kBack;
         if (j == 2u) { ok[0] &= kBack; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
-        vkl::windows<K>(ch, lb.C, ok, [&](uint32_t field4) { atomicAdd(&hist[pair_reverse(field4 >> 2, K)], 1u); }, [] {});
+        if constexpr (LDSH) {
+            uint32_t pa;
+            unsigned long long pm;
+            windows_lds<K>(ch, lb.C, ok, lhist_base, pa, pm);
+        } else {
+            vkl::windows<K>(ch, lb.C, ok, [&](uint32_t field4) { atomicAdd(&hist[pair_reverse(field4 >> 2, K)], 1u); }, [] {});
+        }
         if constexpr (INDEX) {   // the lane's own block (j = 1): its anchors, its sequence bytes
             const bool mine = live && j == 1u;
             uint32_t mlo, mhi;
@@ -1144,10 +1168,18 @@ __global__ __launch_bounds__(256) void vk_aside_kernel(const uint8_t* __restrict
     }
     if constexpr (INDEX) {
         const uint32_t tot = lane_bcast(wave_inclusive_sum(isites), 63);
-        if (lane == 0u) {
+        if (lane == 0u && naside != 0u) {
             ip.count[gw] = nanch;
             if (tot != 0u) atomicAdd(&ip.sites[smp], static_cast<unsigned long long>(tot));
             if (ifull) atomicOr(&ip.overflow[smp], 1u);
+        }
+    }
+    if constexpr (LDSH) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
+        __syncthreads();
+        for (uint32_t code = tid; code < NCODE; code += kCountThreads) {
+            const uint32_t v = lhist[pair_reverse(code, K)];
+            if (v) atomicAdd(&hist[code], v);
         }
     }
 }

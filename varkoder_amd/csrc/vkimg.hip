@@ -220,14 +220,14 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
                                static_cast<uint32_t>(cap), d_aside_n, *index);
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K, true>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
+            hipLaunchKernelGGL((vk_aside_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, *index);
         } else {
             hipLaunchKernelGGL((vk_count_dense_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
                                static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(static_cast<uint32_t>((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, d_fastq,
+            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
         }
     }
@@ -328,7 +328,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
             hipLaunchKernelGGL(vk_pack_kernel, dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq, d_offs + s0,
                                d_lens + s0, n, parts, pk, wph0, ctx->d_aside, aside_cap, d_aside_n);
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3((n * parts * kWaves + 3) / 4), dim3(256), 0, ctx->stream, d_fastq,
+            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n, IndexParams{});
             VK_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL((vk_bucket_kernel<K, 2>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,

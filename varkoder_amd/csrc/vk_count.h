@@ -1347,8 +1347,13 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                             const uint32_t ln = lane_now();
                             const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));   // lanes set aside below this one
                             const bool before = ln == 0u ? aside63 != 0u : ((am >> (ln - 1u)) & 1ull) != 0ull;
-                            alist[naside + below] = ((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph;
-                            r0 = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);   // the separator
+                            // (a buffer store: with a 64-bit address in registers the branch spilled two register pairs and
+                            // waited for them -- and for this store -- with vmcnt(0): 6 % of wave time on fastp-shaped reads)
+                            const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(alist, 0, static_cast<int>(aside_cap * 4u), 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b32(((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph, arsrc, (naside + below) * 4u, 0, 0);
+                            uint32_t nl4;   // the separator (made here: as a loop invariant hipcc kept the constant in scratch)
+                            asm volatile("v_mov_b32 %0, 0x0a0a0a0a" : "=v"(nl4));
+                            r0 = make_uint4(nl4, nl4, nl4, nl4);
                             s = 0u;
                             e = 15u;
                         }

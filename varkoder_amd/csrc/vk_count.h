@@ -1377,6 +1377,11 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 }
             }
             if (!fast) aside63 = 0u;
+            // The rounds of the piece that are counted behind the next piece's loads: none (mode 0), qb (1), qa and qb (2).
+            // One load site for every way through the iteration: with one per branch the piece's sixteen registers met in
+            // phi nodes and the back edge carried a dozen moves.
+            uint32_t mode = 0u, tot = 0u;
+            uint4 qa = make_uint4(0u, 0u, 0u, 0u), qb = qa;
             if (!fast) {
                 // ---- general path (a function of its own: inlined, its register needs -- all 64 bytes
                 // classified at once -- would spill the fast path's loop invariants) ----
@@ -1398,57 +1403,55 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 pph = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.pph)));
                 hot = __builtin_amdgcn_readfirstlane(static_cast<int>(gs.hot)) != 0;
                 tick = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.tick)));
-                if (it + 1 < npieces) load_piece(it + 1);
-                continue;
-            }
-            // ---- hand the granules with sequence bytes to the heavy stage, 64 at a time ----
-            const uint32_t gs = vkl::span_first(s), n = vkl::span_count(s, e);
-            const uint32_t incl = wave_inclusive_sum(n);
-            const uint32_t tot = npend + lane_bcast(incl, 63);
-            const uint32_t first = npend + incl - n - gs;  // + g = the granule's place in the stream (64 per round)
-            // place and round of every granule of this lane (0xFFFF....: none of its rounds)
-            uint32_t wp[4];
+                total = 0u;   // (pph is the general path's)
+            } else {
+                // ---- hand the granules with sequence bytes to the heavy stage, 64 at a time ----
+                const uint32_t gs = vkl::span_first(s), n = vkl::span_count(s, e);
+                const uint32_t incl = wave_inclusive_sum(n);
+                tot = npend + lane_bcast(incl, 63);
+                const uint32_t first = npend + incl - n - gs;  // + g = the granule's place in the stream (64 per round)
+                // place and round of every granule of this lane (0xFFFF....: none of its rounds)
+                uint32_t wp[4];
 #pragma unroll
-            for (uint32_t g = 0; g < 4; ++g) wp[g] = (g - gs < n) ? first + g : 0xFFFFFFC0u;
-            // the start tag is set on the granule's copy in the buffer (the piece's registers stay as loaded:
-            // four aligned 128-bit tuples the stores can take as they are)
-            const uint32_t wtag = vkl::span_starts_inside(s) ? first + gs : 0xFFFFFFC0u;
-            const uint32_t rounds = tot >> 6;
-            auto put = [&](uint32_t r) __attribute__((always_inline)) {  // the granules whose round is r
-                if ((wp[0] >> 6) == r) xb[wp[0] & 63u] = r0;
-                if ((wp[1] >> 6) == r) xb[wp[1] & 63u] = r1;
-                if ((wp[2] >> 6) == r) xb[wp[2] & 63u] = r2;
-                if ((wp[3] >> 6) == r) xb[wp[3] & 63u] = r3;
-                if ((wtag >> 6) == r) atomicOr(&xb[wtag & 63u].x, vkl::kGranuleStartTag);
-            };
-            if (rounds >= 2u) {
+                for (uint32_t g = 0; g < 4; ++g) wp[g] = (g - gs < n) ? first + g : 0xFFFFFFC0u;
+                // the start tag is set on the granule's copy in the buffer (the piece's registers stay as loaded:
+                // four aligned 128-bit tuples the stores can take as they are)
+                const uint32_t wtag = vkl::span_starts_inside(s) ? first + gs : 0xFFFFFFC0u;
+                const uint32_t rounds = tot >> 6;
+                auto put = [&](uint32_t r) __attribute__((always_inline)) {  // the granules whose round is r
+                    if ((wp[0] >> 6) == r) xb[wp[0] & 63u] = r0;
+                    if ((wp[1] >> 6) == r) xb[wp[1] & 63u] = r1;
+                    if ((wp[2] >> 6) == r) xb[wp[2] & 63u] = r2;
+                    if ((wp[3] >> 6) == r) xb[wp[3] & 63u] = r3;
+                    if ((wtag >> 6) == r) atomicOr(&xb[wtag & 63u].x, vkl::kGranuleStartTag);
+                };
                 // The last two rounds' granules are taken out of the buffer first, so that the piece's registers are
                 // free -- and the next piece's loads in flight -- under the arithmetic of BOTH rounds (-0.5 % on 512
                 // distinct samples; the 9 % such a launch loses against one on 64 samples, whose lines the
                 // workgroups of an XCD share in L2, is not the loads' latency).
-                for (uint32_t r = 0; r + 2u < rounds; ++r) {
+                uint32_t r = 0u;
+                for (; r + 2u < rounds; ++r) {
                     put(r);
                     const uint4 q = xb[lane];
                     round_count(64u, q, false);
                 }
-                put(rounds - 2u);
-                const uint4 qa = xb[lane];
-                put(rounds - 1u);
-                const uint4 qb = xb[lane];
-                put(rounds);          // what is left stays in the buffer for the next piece
-                load_piece(it + 1);   // (it + 1 < npieces on this path)
-                round_count(64u, qa, false);
-                round_count(64u, qb, true);
-            } else if (rounds == 1u) {
-                put(0u);
-                const uint4 q = xb[lane];
-                put(1u);
-                load_piece(it + 1);
-                round_count(64u, q, true);
-            } else {
-                put(0u);
-                load_piece(it + 1);
+                if (rounds >= 2u) {
+                    put(r);
+                    qa = xb[lane];
+                    ++r;
+                    mode = 2u;
+                }
+                if (rounds >= 1u) {
+                    put(r);
+                    qb = xb[lane];
+                    ++r;
+                    if (mode == 0u) mode = 1u;
+                }
+                put(r);               // what is left stays in the buffer for the next piece
             }
+            if (it + 1 < npieces) load_piece(it + 1);
+            if (mode == 2u) round_count(64u, qa, false);
+            if (mode != 0u) round_count(64u, qb, true);
             npend = tot & 63u;
             pph += total;
         }

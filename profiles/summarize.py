@@ -19,7 +19,11 @@ src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 shutil.copyfile(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
-for name in ("bench_trace.json",):
+for sub, out in (("trace_d2", "kernel_stats_dist2.csv"), ("trace_ladder", "kernel_stats_ladder.csv")):
+    f = os.path.join(src, sub, "trace_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copyfile(f, os.path.join(dst, out))
+for name in ("bench_trace.json", "bench_trace_d2.json", "ladder.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copyfile(os.path.join(src, name), os.path.join(dst, name))
 

@@ -1370,8 +1370,12 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                         const uint32_t nh = static_cast<uint32_t>(__builtin_popcountll(hm));
                         const uint32_t ln = lane_now();
                         if (nanch + nh > icap) ifull = true;
-                        else if (has) iseg[nanch + static_cast<uint32_t>(__builtin_popcountll(hm & ((1ull << ln) - 1ull)))] =
-                                 static_cast<uint32_t>(o0) + it * static_cast<uint32_t>(kPiece) + 64u * ln + s_raw - 1u;
+                        else if (has) {   // (a buffer store, as for the lanes set aside: no 64-bit address in vector registers)
+                            const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(iseg, 0, static_cast<int>(icap * 4u), 0x00020000);
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hm), 0u));
+                            __builtin_amdgcn_raw_buffer_store_b32(static_cast<uint32_t>(o0) + it * static_cast<uint32_t>(kPiece) + 64u * ln + s_raw - 1u,
+                                                                  irsrc, (nanch + rank) * 4u, 0, 0);
+                        }
                         if (!ifull) nanch += nh;
                     }
                 }

@@ -205,10 +205,10 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                            d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, SubParams{});
     else {
         ctx->last_lds = (1u << (2 * K)) * 4u + kWaves * 1024;
-        // the waves' lists of lanes set aside (vk_count.h): room for one lane in every second piece of the longest
-        // range, at least 64 entries; a wave whose list is full sends its pieces down the general path instead
+        // the waves' lists of lanes set aside (vk_count.h): room for one lane per piece of the longest range (fastp-shaped
+        // reads need 0.45), at least 64 entries; a wave whose list is full sends its pieces down the general path instead
         const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
-        uint64_t cap = wave_bytes / (2 * kPiece) + 64;
+        uint64_t cap = wave_bytes / kPiece + 64;
         if (cap > (1u << 20)) cap = 1u << 20;
         const size_t nwaves = static_cast<size_t>(grid) * kWaves;
         const size_t need = nwaves * (cap + 1) * sizeof(uint32_t);   // lists, then their lengths
@@ -299,7 +299,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         VK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (base is a temporary; once per call)
         // the waves' lists of lanes set aside, as for the k <= 7 kernel
         const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
-        uint64_t cap = wave_bytes / (2 * kPiece) + 64;
+        uint64_t cap = wave_bytes / kPiece + 64;
         if (cap > (1u << 20)) cap = 1u << 20;
         aside_cap = static_cast<uint32_t>(cap);
         const size_t nwaves = static_cast<size_t>(batch) * parts * kWaves;

@@ -69,6 +69,8 @@ def parse():
                     "(256 x 560k x 150 bp = 21.5 Gbases: about a second per pass)")
     ap.add_argument("--e2e-passes", type=int, default=3)
     ap.add_argument("--e2e-files-per-rank", type=int, default=24, help="files of the end-to-end leg at N > 1 (per rank)")
+    ap.add_argument("--e2e-io-threads", type=int, default=0, help="I/O threads per rank of the N > 1 end-to-end leg (0 = this "
+                    "rank's share of the usable cores; a rehearsal with fewer ranks than the node has GPUs sets the node's share)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this "
                     "process may use: physical cores, capped by affinity and the cgroup's CPU quota)")
@@ -312,7 +314,7 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
     from varkoder_amd import pipeline
     from varkoder_amd.shard import usable_cores
     nfiles, reads = args.e2e_files_per_rank, args.e2e_reads
-    threads = max(1, usable_cores() // world)
+    threads = args.e2e_io_threads if args.e2e_io_threads > 0 else max(1, usable_cores() // world)
     tmp = Path(tempfile.mkdtemp(prefix="vk_e2e_r%d_" % rank))
 
     def everyone(ok):

@@ -15,7 +15,7 @@ from varkoder_amd.engine import ImageEngine  # noqa: E402
 
 eng = ImageEngine(k=7, mapping="varKode")
 bad = 0
-for dist in (0, 1):
+for dist in (0, 1, 2):
     n = 12
     fq, offs, lens = eng.synth(3000 + 100 * dist, n, 1_000_000, 150, dist=dist)
     host = fq.cpu().numpy()

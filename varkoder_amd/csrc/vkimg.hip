@@ -848,8 +848,16 @@ int vk_image_device(vk_ctx* ctx, const uint32_t* d_hist, uint32_t nsamples, int 
     if (npad > kTile && !ctx->image_sort_only) {
         // large images: order statistics by counting; samples it cannot finish are flagged for the sort
         uint32_t* flags = ctx->d_scratch + work / sizeof(uint32_t);
+        // the scatter first, spread over the device (vk_image.h); a batch too large for one grid keeps it in the kernel
+        const int scattered = nsamples <= 65535u ? 1 : 0;
+        if (scattered) {
+            VK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0, work, ctx->stream));
+            hipLaunchKernelGGL(vk_image_scatter_kernel, dim3((1u << (2 * k)) / 256u, nsamples), dim3(256), 0, ctx->stream, d_hist,
+                               ctx->d_pix[k], k, npad, ctx->d_scratch);
+            VK_HIP(ctx, hipGetLastError());
+        }
         hipLaunchKernelGGL(vk_image_count_kernel, dim3(nsamples), dim3(kImgThreads), 0, ctx->stream, d_hist,
-                           ctx->d_pix[k], k, npix, npad, ctx->d_scratch, d_img, flags);
+                           ctx->d_pix[k], k, npix, npad, ctx->d_scratch, d_img, flags, scattered);
         VK_HIP(ctx, hipGetLastError());
         gate = flags;
     }

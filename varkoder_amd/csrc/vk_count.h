@@ -1568,7 +1568,9 @@ constexpr uint32_t kLdsAbove = kLdsBelow + 66 * 16;               // uint4 [66]
 constexpr uint32_t kLdsQueues = 8192;                             // u16 [kWaves][16][128]
 constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // uint2 [kWaves][64]: (codes, OK) of lane groups on their way to the append stage
 constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
-static_assert(kLdsAbove + 66 * 16 <= kLdsQueues, "LDS layout");
+constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
+constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
+static_assert(kLdsPool + kWaves * 8 <= kLdsQueues, "LDS layout");
 static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");  // = exactly 160 KiB
 
 // Raw window field (first base least significant) of the window of type t (0: ends at p, 1: ends at
@@ -1636,6 +1638,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         qrun_all[wave * kQueues + lane] = 0u;
         qused_all[wave * kQueues + lane] = kNoRun;
     }
+    if (lane < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsPool)[wave * 2 + lane] = 0u;   // an empty reserve
     __syncthreads();
 
     const uint8_t* sbase = fastq + offs[s];
@@ -1670,8 +1673,30 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             hdrs[run] = 0x80000000u | (used << 8) | q;
             atomicAdd(&bp.bsize[s * kQueues + q], used);
         }
+        // A queue that needs a new run takes it from the wave's reserve (kPoolRuns runs per returning atomic on the
+        // sample's cursor): one run per atomic made four drains in ten wait out a round trip to the memory-side atomic
+        // unit -- and, vmcnt being one counter, every store still in flight.  What is left of a reserve that cannot
+        // serve a drain's requests is abandoned: a run that is never closed has no header and pass B skips it.
         uint32_t nrun = 0;
-        if (need && sub == 0) nrun = atomicAdd(cursor, 1u);
+        const unsigned long long needm = __ballot(need && sub == 0);
+        if (needm != 0ull) {
+            uint32_t* const pool = reinterpret_cast<uint32_t*>(ldsb + kLdsPool) + static_cast<uint32_t>(wave) * 2u;
+            const uint32_t want = static_cast<uint32_t>(__builtin_popcountll(needm));   // <= 16 = kPoolRuns
+            uint32_t next = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pool[0])));
+            uint32_t end = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pool[1])));
+            if (next + want > end) {
+                uint32_t got = 0;
+                if (lz == 0u) got = atomicAdd(cursor, kPoolRuns);
+                next = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(got)));
+                end = next + kPoolRuns;
+            }
+            if (need && sub == 0)
+                nrun = next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(needm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(needm), 0u));
+            if (lz == 0u) {
+                pool[0] = next + want;
+                pool[1] = end;
+            }
+        }
         nrun = quad_bcast0(nrun);
         if (need) {
             run = nrun;
@@ -1680,12 +1705,19 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         const bool store = used + nb <= kRunBlocks;
         const uint4* src = reinterpret_cast<const uint4*>(qdata) + sub;
         uint4* dst = reinterpret_cast<uint4*>(arena + static_cast<uint64_t>(run) * kRunBytes + used * kBlockBytes) + sub;
+        // (the queue's first two blocks are read together, whether full or not -- a drain seldom finds more: one LDS
+        // round trip, not one per block; all four at once cost a spilled quad at 64 registers)
+        const uint4 blk0 = src[0], blk1 = src[4];
 #pragma unroll
         for (uint32_t b = 0; b < kQueueBlocks; ++b) {
             if (b < nb) {
-                const uint4 v = src[b * 4u];
+                const uint4 v = b == 0 ? blk0 : (b == 1 ? blk1 : src[b * 4u]);
                 if (store) {
+#ifdef VK_DIAG_K9_NO_STORE   // timing only: the drain with everything but its stores to the arena
+                    asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(dst));
+#else
                     dst[b * 4u] = v;
+#endif
                 } else {  // no room in the arena: count these entries directly (exact, slow; kept small)
                     const uint16_t* e16 = reinterpret_cast<const uint16_t*>(qdata) + b * (kBlockBytes / 2) + sub * 8u;
 #pragma nounroll

@@ -244,7 +244,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     // pairs (sequence lines are less than half of the text), so len / 2 bytes however the pairs spread
     // over the 16 buckets; plus the blocks a drain may leave unused at the end of a run (at most 3 of
     // 64), plus one open run per (workgroup, wave, queue).
-    uint64_t runs = (maxlen / 2 + maxlen / 32) / kRunBytes + 16 + static_cast<uint64_t>(parts) * kWaves * kQueues;
+    uint64_t runs = (maxlen / 2 + maxlen / 16) / kRunBytes + 16 + static_cast<uint64_t>(parts) * kWaves * (kQueues + kPoolRuns);   // (+ one open run per queue and one reserve per wave)
     if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
     if (runs >= (1u << 24)) return VK_EINVAL;             // a run number travels in 24 bits (64 GiB of entries per sample)
     constexpr size_t kBucketHistBytes = static_cast<size_t>(kQueues) * (2u << (2 * K - 4)) * sizeof(uint32_t);  // pass B -> merge

@@ -113,6 +113,40 @@ def test_sampled_count_matches_the_oracle(k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [8, 9])
+def test_walker_at_k8_and_k9(k):
+    """k = 8, 9: the walker takes a call only when every threshold is a few per cent of the reads (the library's rule,
+    kWalkMaxThresholdSpill) -- the calls of the test above hold larger ones and stream.  Small fractions over samples
+    large enough to have reads taken, several splits; the launch must be the walker's (its LDS holds no bucket queues)."""
+    eng = _engine(k)
+    blobs = [synth.sample_fastq(11 + d, 20000, 150, dist=d).tobytes() for d in range(3)]
+    blobs.append(b"".join(fastq_cases.rec(f"L{i}", fastq_cases.rand_seq(np.random.default_rng(i), 1700)) for i in range(400)))
+    blobs.append(fastq_cases.random_fastq(np.random.default_rng(77), 3000))
+    fq, offs, lens = eng.upload(blobs)
+    for parts in (0, 1, 3):
+        nsites, status = eng.read_index(fq, offs, lens, parts=parts)
+        assert not status.any()
+        pairs = [(i, seed, den) for i in range(len(blobs)) for seed, den in ((7, 33), (8, 100), (9, 400))]
+        idx = [i for i, _, _ in pairs]
+        seeds = np.array([s_ for _, s_, _ in pairs], dtype=np.uint64)
+        thr = np.array([(1 << 32) // den for _, _, den in pairs], dtype=np.uint64)
+        assert int(thr.max()) <= subsample.WALK_MAX_THRESHOLD_SPILL
+        hist, st, sites = eng.count_sampled(fq, offs[idx], lens[idx], seeds, thr)
+        assert eng.last_count_launch()["lds_bytes"] < 16384            # the walker, not the spill path
+        h = hist.cpu().numpy().view(np.uint32)
+        si = sites.cpu().numpy()
+        assert not st.cpu().numpy().any()
+        taken = 0
+        for j, (i, seed, den) in enumerate(pairs):
+            want, nwin, wst, wsites = oracle.count_fastq_sampled(blobs[i], k, seed, int(thr[j]))
+            assert tuple(int(x) for x in si[j]) == wsites, (j, i, seed, den, parts)
+            assert int(h[j].sum(dtype=np.uint64)) == nwin and np.array_equal(h[j], want), (j, i, seed, den, parts)
+            taken += nwin
+        assert taken > 10000
+    eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [5, 7, 9])
 def test_read_index_and_walker_match_the_oracle(k):
     """vk_read_index_device + the walker (vk_ladder.h): the same subsampled counts and sites as the streaming kernel and

@@ -162,26 +162,31 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_walk_kernel(
         // of the sector before for lane 0), takes out the windows that would span a multiple of 500 bases of the read,
         // and counts its 16 positions' windows with the hand-written block of the k <= 7 kernels (windows_lds1) or, for
         // k = 8, 9, one by one into the subsample's row.
-        const uint64_t len16 = (len + 15ull) & ~15ull;
+        // (positions as 32-bit offsets: an indexed sample is shorter than 4 GiB less a margin -- vkimg.hip count_walk)
+        const uint32_t len32 = static_cast<uint32_t>(len), len16 = (len32 + 15u) & ~15u;
         const uint32_t g = static_cast<uint32_t>(lane) & 3u;
         auto walk = [&](uint32_t nb) __attribute__((always_inline)) {
             for (uint32_t sb = 0; sb < nb; sb += 16u) {
                 const uint32_t r = sb + (static_cast<uint32_t>(lane) >> 2);
                 bool active = r < nb;
-                const uint64_t p = active ? static_cast<uint64_t>(q[r]) + 1ull : 0ull;   // first byte of the sequence line
-                if (p >= len) active = false;
-                uint64_t at = (p & ~63ull) + 16ull * g;      // this lane's granule of the read's first sector
+                const uint32_t p = active ? q[r] + 1u : 0u;   // first byte of the sequence line
+                if (p >= len32) active = false;
+                uint32_t at = (p & ~63u) + 16u * g;          // this lane's granule of the read's first sector
                 // read position of the granule's position 0, modulo 500 (negative before the read's first byte)
-                uint32_t r500 = at >= p ? static_cast<uint32_t>(at - p) : vkl::kBreakLength - static_cast<uint32_t>(p - at);
+                uint32_t r500 = at >= p ? at - p : vkl::kBreakLength - (p - at);
                 uint32_t carry_c = 0u, carry_bad = 0x55555555u;
+                // positions before the read's first byte: in its first sector only (the reads of a batch start together)
+                const int d0 = static_cast<int>(p - at);
+                uint32_t below_start = d0 <= 0 ? 0u : (d0 >= 16 ? 0xFFFFFFFFu : ((1u << (2u * static_cast<uint32_t>(d0))) - 1u));
                 while (__any(active)) {
                     uint4 v = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
                     if (active && at < len16) v = *reinterpret_cast<const uint4*>(sbase + at);
                     uint32_t C, IV, NL;
-                    vkl::classify_granule_any(v.x, v.y, v.z, v.w, C, IV, NL);
-                    // positions before the read's first byte, positions at and beyond the end of the text
-                    const uint32_t below_start = at >= p ? 0u : (at + 16ull <= p ? 0xFFFFFFFFu : ((1u << (2u * static_cast<uint32_t>(p - at))) - 1u));
-                    const uint32_t below_end = at + 16ull <= len ? 0xFFFFFFFFu : (at >= len ? 0u : ((1u << (2u * static_cast<uint32_t>(len - at))) - 1u));
+                    if (__any(((v.x | v.y | v.z | v.w) & 0x80808080u) != 0u)) vkl::classify_granule_nl<false>(v.x, v.y, v.z, v.w, C, IV, NL);
+                    else vkl::classify_granule_nl<true>(v.x, v.y, v.z, v.w, C, IV, NL);
+                    // positions at and beyond the end of the text (the last sector of a sample only)
+                    uint32_t below_end = 0xFFFFFFFFu;
+                    if (__any(at + 16u > len32)) below_end = at + 16u <= len32 ? 0xFFFFFFFFu : (at >= len32 ? 0u : ((1u << (2u * (len32 - at))) - 1u));
                     const uint32_t stop = (NL | ~below_end) & ~below_start & 0x55555555u;   // line ends at or behind the first byte
                     // has the line ended in a granule of this sector before mine?
                     const unsigned long long sm = __ballot(active && stop != 0u);
@@ -189,6 +194,10 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_walk_kernel(
                     const bool over = (quad & ((1u << g) - 1u)) != 0u;
                     const uint32_t low = (stop - 1u) & ~stop;                  // everything below my first line end (all ones without one)
                     const uint32_t SEQ = (active && !over) ? (low & ~below_start) : 0u;
+                    below_start = 0u;
+                    // (opaque to the optimiser: without this the k = 8, 9 instantiations -- and only those -- counted a few
+                    // windows too many or too few per sample, hipcc 7.2; tests/test_subsample.py::test_walker_at_k8_and_k9)
+                    asm volatile("" : "+v"(below_start));
                     taken_sites += vkl::popc(SEQ & 0x55555555u);
                     const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
                     const uint32_t c_before = dpp_or_zero<0x111, 0xF>(C), bad_before = dpp_or_zero<0x111, 0xF>(bad);   // row_shr:1: the lane before
@@ -222,8 +231,8 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_walk_kernel(
                         vkl::windows1<K>(prev_c, C, ok, [&](uint32_t field4) { atomicAdd(&out[pair_reverse(field4 >> 2, K)], 1u); });
                     }
                     r500 = r500 + 64u >= vkl::kBreakLength ? r500 + 64u - vkl::kBreakLength : r500 + 64u;
-                    at += 64ull;
-                    if (quad != 0u || (at & ~63ull) >= len) active = false;   // the line ended in this sector, or the text did
+                    at += 64u;
+                    if (quad != 0u || (at & ~63u) >= len32) active = false;   // the line ended in this sector, or the text did
                 }
             }
         };

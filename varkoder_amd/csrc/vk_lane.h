@@ -620,7 +620,9 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
 
 // The same for any bytes (no ASCII precondition), with the newline flags instead of a sequence mask: the subsample
 // walker (vk_ladder.h) knows where its read starts and only asks where it ends.
-VKL_FN void classify_granule_any(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout, uint32_t& NLout) {
+// ASCII: the caller has seen that no byte of the wave's granules has bit 7 set (the byte tests of classify_granule).
+template <bool ASCII>
+VKL_FN void classify_granule_nl(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout, uint32_t& NLout) {
     constexpr uint32_t kLutLo = 0x41204020u, kLutHi = 0x42202053u;  // as in classify()
     const uint32_t k7f = 0x7F7F7F7Fu;
     const uint32_t p01l = perm(a1, a0, 0x05010400u), p01h = perm(a1, a0, 0x07030602u);
@@ -636,14 +638,18 @@ VKL_FN void classify_granule_any(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t
         const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
         const uint32_t x = xor_and_k(L, t, 0xD8D8D8D8u);
         C = j == 0 ? (x & 0x03030303u) : lshl_or(x & 0x03030303u, 2 * j, C);
-        const uint32_t nz = ((x & 0x7C7C7C7Cu) + k7f) | x;
-        const uint32_t eq = ~(xor_add_k(t & k7f, 0x0A0A0A0Au, k7f) | t);
+        const uint32_t nz = ASCII ? x + 0x7C7C7C7Cu : (((x & 0x7C7C7C7Cu) + k7f) | x);
+        const uint32_t eq = ASCII ? xor_add_k(t, 0x75757575u, 0x01010101u) : ~(xor_add_k(t & k7f, 0x0A0A0A0Au, k7f) | t);
         IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
         NL = j == 0 ? ((eq >> 7) & 0x01010101u) : and_or_k(eq >> (7 - 2 * j), 0x01010101u << (2 * j), NL);
     }
     Cout = C;
     IVout = IV;
     NLout = NL;
+}
+
+VKL_FN void classify_granule_any(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& IVout, uint32_t& NLout) {
+    classify_granule_nl<false>(a0, a1, a2, a3, Cout, IVout, NLout);
 }
 
 // OK of the 16 positions of one granule (even bits) from its BAD string and the one before it.

@@ -569,6 +569,7 @@ static int count_walk(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
         if (k > 7 && thresholds[i] > kWalkMaxThresholdSpill) return VK_OK;
         const auto it = ctx->ix_sample.find(std::make_pair(offsets[i], lengths[i]));
         if (it == ctx->ix_sample.end() || ctx->ix_overflow[it->second]) return VK_OK;   // not indexed: the streaming kernels
+        if (lengths[i] >= (1ull << 32) - 4096) return VK_OK;                             // (the walker's offsets are 32-bit)
         isample[i] = it->second;
         status[i] = ctx->ix_status[it->second];
     }

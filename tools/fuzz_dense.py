@@ -75,4 +75,31 @@ for k in (5, 6, 7):
         print(f"k={k} round {r}: {nblobs} inputs, {sum(len(b) for b in blobs) / 1e6:.0f} MB, parts {parts}, "
               f"general-path pieces {general}, mismatches so far {bad}", flush=True)
     eng.close()
+# k = 8, 9: the spill path on the same kind of input, and the walker on small fractions (the only calls it takes there)
+for k in (8, 9):
+    eng = ImageEngine(k=k, mapping="cgr")
+    rng = np.random.default_rng(4000 + k)
+    for r in range(max(1, rounds // 4)):
+        blobs = [big_blob(rng) for _ in range(nblobs)]
+        fq, offs, lens = eng.upload(blobs)
+        parts = int(rng.integers(1, 4))
+        hist, status = eng.count(fq, offs, lens, parts=parts)
+        h = hist.cpu().numpy().view(np.uint32)
+        st = status.cpu().numpy()
+        nsites, sti = eng.read_index(fq, offs, lens, parts=parts)
+        seed, thr = int(rng.integers(0, 2 ** 40)), int(rng.integers(1, 2 ** 32 // 32))
+        hs, sts, sites = eng.count_sampled(fq, offs, lens, seed, thr, parts=parts)
+        walker = eng.last_count_launch()["lds_bytes"] < 16384
+        hs = hs.cpu().numpy().view(np.uint32)
+        si = sites.cpu().numpy()
+        for i, b in enumerate(blobs):
+            want, _, wst = oracle.count_fastq(b, k)
+            ws, _, wsst, wsites = oracle.count_fastq_sampled(b, k, seed, thr)
+            ok = wst == 0 and st[i] == 0 and sti[i] == 0 and np.array_equal(h[i], want) and int(nsites[i]) == wsites[0] and \
+                np.array_equal(hs[i], ws) and tuple(int(x) for x in si[i]) == wsites
+            if not ok:
+                bad += 1
+                print("MISMATCH", k, r, i, len(b), parts, seed, thr, bool(np.array_equal(h[i], want)), bool(np.array_equal(hs[i], ws)), flush=True)
+        print(f"k={k} round {r}: {nblobs} inputs, parts {parts}, walker {walker}, mismatches so far {bad}", flush=True)
+    eng.close()
 sys.exit(1 if bad else 0)

@@ -1542,7 +1542,11 @@ constexpr uint32_t kBlockBytes = 64;      // drain unit
 constexpr uint32_t kQueueBlocks = kQueueBytes / kBlockBytes;
 constexpr uint32_t kRunBytes = 4096;      // arena allocation unit
 constexpr uint32_t kRunBlocks = kRunBytes / kBlockBytes;
-constexpr uint32_t kDrainAt = 2 * kBlockBytes;  // inside a piece: drain when some queue holds this many bytes
+// Inside a piece the queues are drained when one holds this many bytes: three blocks while the wave has not seen a queue
+// overflow, two from its first overflow on.  Three for good is -1.3 % on uniform bases and -5 % on fastp-shaped reads but
+// +20 % on GC-skewed ones, whose queues overflow into global atomics (profiles/ab/r04_k9_drain_threshold.txt).
+constexpr uint32_t kDrainAt = 2 * kBlockBytes;
+constexpr uint32_t kDrainAtCalm = 3 * kBlockBytes;
 constexpr uint32_t kNoRun = 0x100;        // "blocks used" of a queue that has no run open
 
 struct BucketParams {
@@ -1830,6 +1834,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         // The append stage of one lane group (16 positions): lo = codes of the 16 positions before it, hi = its own,
         // okg = its OK string.
         bool hot = false;
+        uint32_t drain_at = kDrainAtCalm;   // (wave-uniform; lowered for good by the first overflow)
         uint32_t xpend = 0, xctx = 0;  // dense stage: groups waiting in the exchange buffer, codes of the last group appended
         auto append_group = [&](uint32_t lo, uint32_t hi, uint32_t okg) __attribute__((always_inline)) {
             // bit 4j of `both` / `one`: both / exactly one of the windows ending at 2j, 2j + 1 count
@@ -1846,7 +1851,10 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                     f[j] = both & (1u << (16 * h + 4 * j));
                 }
                 const uint32_t full = append4(x, f);
-                if (__any(full != 0u)) hot = true;
+                if (__any(full != 0u)) {
+                    hot = true;
+                    drain_at = kDrainAt;
+                }
                 if (full) {  // rare: the queue was full, count the pair directly
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -1899,7 +1907,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 for (int g = 0; g < 4; ++g) {
                     if (__any(okl[g] != 0u)) {  // wave-uniform: a group of sixteen positions without any window is common (MODE 1)
                         append_group(v[g], v[g + 1], okl[g]);
-                        if (g == 1) maybe_drain(kDrainAt);  // inside a piece only a queue that is filling up fast is drained (skewed bases)
+                        if (g == 1) maybe_drain(drain_at);  // inside a piece only a queue that is filling up fast is drained (skewed bases)
                     }
                 }
             } else {
@@ -1945,7 +1953,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                     if (lane < static_cast<int>(kQueues)) qcnt[lane] = 0u;   // timing only: the queues are thrown away
                     wave_lds_fence();
 #else
-                    maybe_drain(kDrainAt);
+                    maybe_drain(drain_at);
 #endif
                 }
                 xpend = tot & 63u;

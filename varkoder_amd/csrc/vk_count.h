@@ -1750,6 +1750,18 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
     };
 
     uint32_t ph_start = 0, ph_end = 0;
+#ifdef VK_DIAG_K9_BARRIER
+    uint32_t diag_nbar = 0;
+    {
+        uint32_t* const slot = reinterpret_cast<uint32_t*>(ldsb + kLdsPool) + kWaves * 2;   // (a free word behind the pools)
+        if (tid == 0) *slot = 0xFFFFFFFFu;
+        __syncthreads();
+        const uint32_t np = wr.empty ? 0u : static_cast<uint32_t>((wr.w1 - (wr.w0 ? wr.w0 - 64 : 0)) / kPiece);
+        if (lane == 0) atomicMin(slot, np);
+        __syncthreads();
+        diag_nbar = *slot;
+    }
+#endif
     if (!wr.empty) {
         const uint32_t wbase = static_cast<uint32_t>(wave) * (kQueues * 4u);  // this wave's counters, relative to kLdsCnt
         const uint32_t two = 2u;
@@ -1763,7 +1775,11 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // counter offset: q * 4 + this wave's base; entry: shared-prefix bits | base p+1
+#ifdef VK_DIAG_K9_NOCONFLICT    // timing only: the queue by the lane's number, two lanes per counter in every half-wave
+                c[j] = ((static_cast<uint32_t>(lane) & 15u) << 2) | wbase;
+#else
                 c[j] = ((x[j] >> (2 * K - 6)) & 0x3Cu) | wbase;
+#endif
                 e[j] = (x[j] & LMASK) | ((x[j] >> 4) & ~LMASK);  // one v_bfi: base p+1 moves down over the four bucket bits (garbage above it)
             }
             uint32_t a0, a1, a2, a3;
@@ -1822,7 +1838,17 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             else atomicAdd(&hist_s[code], 1u);  // a third single of this lane in one piece (reads full of N)
             ++npend;
         };
+#ifdef VK_DIAG_K9_BARRIER   // timing only: what two workgroup barriers per piece cost
+        uint32_t diag_piece = 0;
+#endif
         auto piece_start = [&](const uint4&) __attribute__((always_inline)) {
+#ifdef VK_DIAG_K9_BARRIER
+            if (diag_piece < diag_nbar) {
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
+            ++diag_piece;
+#endif
             if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
             if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
             npend = 0u;
@@ -1840,8 +1866,13 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             // bit 4j of `both` / `one`: both / exactly one of the windows ending at 2j, 2j + 1 count
             const uint32_t both = okg & (okg >> 2) & 0x11111111u;
             const uint32_t one = (okg ^ (okg >> 2)) & 0x11111111u;
+#ifdef VK_DIAG_K9_HALF_APPEND   // timing only: half of the pairs are dropped
+            constexpr int kHalves = 1;
+#else
+            constexpr int kHalves = 2;
+#endif
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kHalves; ++h) {
                 uint32_t x[4], f[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -1559,6 +1559,12 @@ struct BucketParams {
     uint32_t* wide;      // [nsamples * 16] != 0: the job's u16 pair counters overflowed, bucket_hist holds u32 window counters instead
     uint32_t runs_cap;
     uint32_t force_wide; // tests: every job through the u32 replay
+    // the quad route (MODE 3 of vk_bucket_kernel; bsize / order / wide are not used by it):
+    uint32_t* qfirst;    // [nsamples][kQuadBuckets + 1] first entry of every bucket's runs in qlist (vk_quad_list_kernel)
+    uint32_t* qlist;     // [nsamples][runs_cap] closed runs sorted by bucket: run | filled blocks << 24
+    uint32_t* misc;      // [grid * kWaves][misc_cap] quads of which only some windows count: K + 3 bases | OK bits << 24
+    uint32_t* misc_n;    // [grid * kWaves] entries in each list
+    uint32_t misc_cap;
 };
 
 // LDS of the bucket kernel, one array with fixed offsets (the hand-written queue appends address it
@@ -1574,7 +1580,10 @@ constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // u
 constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
 constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
-static_assert(kLdsPool + kWaves * 8 <= kLdsQueues, "LDS layout");
+constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [2]: the quad route's rounds of a step, agreed by the workgroup
+static_assert(kLdsSync + 8 <= kLdsQueues, "LDS layout");
+constexpr uint32_t kQuadBuckets = 256;    // the quad route's bucket streams per sample = kWaves * kQueues queues per WORKGROUP
+static_assert(kQuadBuckets == kWaves * kQueues, "a wave drains sixteen of its workgroup's queues");
 static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");  // = exactly 160 KiB
 
 // Raw window field (first base least significant) of the window of type t (0: ends at p, 1: ends at
@@ -1598,19 +1607,50 @@ __device__ __forceinline__ void count_entry_direct(uint32_t* hist_s, uint32_t q,
     atomicAdd(&hist_s[pair_reverse(entry_raw<K>(q, (1u << LB) | (rest >> 2) | (last << (LB - 2))), K)], 1u);
 }
 
+// ---- the quad route (vk_bucket_kernel<K, 3>): ONE u16 entry per FOUR windows ----------------------------
+// The windows ending at p .. p + 3 (p a multiple of 4 in the file) span K + 3 bases b0 .. b(K+2) and all hold the four
+// bases b(K-4) .. b(K-1): those are the bucket number (8 bits, 256 streams per sample), and what is left is the entry:
+//     bits [0, 2K - 8)        head: b0 .. b(K-5)
+//     bits [2K - 8, 2K - 2)   tail: b(K), b(K+1), b(K+2)
+// -- half a byte of bucket traffic per window.  256 queues do not fit a wavefront's share of LDS, so the queues belong
+// to the WORKGROUP (256 x 128 entries, the same 64 KiB): every wave appends to all of them with returning LDS atomics
+// and drains sixteen of them (wave w: queues 16 w .. 16 w + 15) at points the workgroup agrees on, between two
+// barriers each -- measured free (profiles/ab/r05_k9_append_diagnostics.txt) -- one before every round of appends.
+// Pass B (vk_quad_count_kernel) counts an entry as two PAIRS (windows 0, 1: the entry's low 2K - 6 bits; windows 2, 3:
+// its high 2K - 6 bits) into two u32 tables of 4^(K-3) counters per bucket; vk_quad_merge_kernel sums per k-mer code.
+// Quads of which only some windows count (a read's first and last, the neighbours of an N: ~1.5 per read) travel as
+// u32 words (K + 3 bases | OK bits << 24) through a list per wavefront in HBM and are counted with global atomics by
+// spare workgroups of pass B's launch.
+// x = the K + 3 bases of a quad (2 bits each, first base lowest; garbage above allowed where noted)
+template <int K>
+__device__ __forceinline__ uint32_t quad_bases(uint32_t q, uint32_t e) {   // bucket q, entry e (garbage above bit 2K - 2 allowed)
+    constexpr uint32_t HB = 2 * K - 8;
+    return (e & ((1u << HB) - 1u)) | (q << HB) | (((e >> HB) & 63u) << (2 * K));
+}
+// the windows of a quad named by the OK bits `okb` (bit 2t: window t), counted directly
+template <int K>
+__device__ __forceinline__ void count_quad_direct(uint32_t* hist_s, uint32_t x, uint32_t okb) {
+    constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t)
+        if ((okb >> (2u * t)) & 1u) atomicAdd(&hist_s[pair_reverse((x >> (2u * t)) & FMASK, K)], 1u);
+}
+
 __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
 }
 
 // MODE 0: the FASTQ text through vk_count_kernel's front end (every byte classified); 1: the same with read
-// subsampling; 2: the packed stream of vk_pack_kernel (no line logic, no classification here: the shipped pass A).
+// subsampling; 2: the packed stream of vk_pack_kernel (no line logic, no classification here); 3: MODE 0's front end
+// with quad entries in workgroup-shared queues (see above: the shipped pass A).
 template <int K, int MODE>
 __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_bucket_kernel(
     const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp, PackParams pk) {
-    constexpr bool SUB = MODE == 1, STREAM = MODE == 2;
+    constexpr bool SUB = MODE == 1, STREAM = MODE == 2, QUAD = MODE == 3;
     constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t NQ = QUAD ? kQuadBuckets : kQueues;   // bucket streams per sample
     constexpr uint32_t LB = 2 * K - 4;               // bits of an entry that come from the shared prefix
     constexpr uint32_t LMASK = (1u << LB) - 1u;
     constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
@@ -1643,6 +1683,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         qused_all[wave * kQueues + lane] = kNoRun;
     }
     if (lane < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsPool)[wave * 2 + lane] = 0u;   // an empty reserve
+    if (tid < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
     __syncthreads();
 
     const uint8_t* sbase = fastq + offs[s];
@@ -1670,12 +1711,13 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         uint32_t lz = static_cast<uint32_t>(lane), nb = nb_;
         asm volatile("" : "+v"(lz));
         const uint32_t q = lz >> 2, sub = lz & 3u;
+        const uint32_t bq = QUAD ? static_cast<uint32_t>(wave) * kQueues + q : q;   // the queue's bucket
         uint8_t* const qdata = ldsb + kLdsQueues + (static_cast<uint32_t>(wave) * kQueues + q) * kQueueBytes;
         uint32_t run = qrun[q], used = qused[q];
         const bool need = nb != 0u && used + nb > kRunBlocks;  // the blocks of one drain stay in one run
         if (need && sub == 0 && used <= kRunBlocks) {  // close the old run
-            hdrs[run] = 0x80000000u | (used << 8) | q;
-            atomicAdd(&bp.bsize[s * kQueues + q], used);
+            hdrs[run] = 0x80000000u | (used << 8) | bq;
+            if constexpr (!QUAD) atomicAdd(&bp.bsize[s * kQueues + q], used);
         }
         // A queue that needs a new run takes it from the wave's reserve (kPoolRuns runs per returning atomic on the
         // sample's cursor): one run per atomic made four drains in ten wait out a round trip to the memory-side atomic
@@ -1725,7 +1767,10 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 } else {  // no room in the arena: count these entries directly (exact, slow; kept small)
                     const uint16_t* e16 = reinterpret_cast<const uint16_t*>(qdata) + b * (kBlockBytes / 2) + sub * 8u;
 #pragma nounroll
-                    for (int j = 0; j < 8; ++j) count_entry_direct<K>(hist_s, q, e16[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (QUAD) count_quad_direct<K>(hist_s, quad_bases<K>(bq, e16[j]), 0x55u);
+                        else count_entry_direct<K>(hist_s, q, e16[j]);
+                    }
                 }
             }
         }
@@ -1762,8 +1807,9 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         diag_nbar = *slot;
     }
 #endif
-    if (!wr.empty) {
-        const uint32_t wbase = static_cast<uint32_t>(wave) * (kQueues * 4u);  // this wave's counters, relative to kLdsCnt
+    // (quad route: the waves of a workgroup meet at barriers, so a wave without a range of its own goes through the block too)
+    if (!wr.empty || QUAD) {
+        const uint32_t wbase = QUAD ? 0u : static_cast<uint32_t>(wave) * (kQueues * 4u);  // this wave's counters, relative to kLdsCnt (quad route: the workgroup's)
         const uint32_t two = 2u;
         // Append four pairs.  x[j] = the K + 1 bases of pair j (2 bits each, first base lowest, garbage
         // above), f[j] != 0 <=> both windows of the pair are countable.  Straight-line code: the lane
@@ -1778,9 +1824,15 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
 #ifdef VK_DIAG_K9_NOCONFLICT    // timing only: the queue by the lane's number, two lanes per counter in every half-wave
                 c[j] = ((static_cast<uint32_t>(lane) & 15u) << 2) | wbase;
 #else
-                c[j] = ((x[j] >> (2 * K - 6)) & 0x3Cu) | wbase;
+                if constexpr (QUAD) c[j] = (x[j] >> (2 * K - 10)) & 0x3FCu;   // bucket = bases K-4 .. K-1 of the quad
+                else c[j] = ((x[j] >> (2 * K - 6)) & 0x3Cu) | wbase;
 #endif
-                e[j] = (x[j] & LMASK) | ((x[j] >> 4) & ~LMASK);  // one v_bfi: base p+1 moves down over the four bucket bits (garbage above it)
+                if constexpr (QUAD) {
+                    constexpr uint32_t HM = (1u << (2 * K - 8)) - 1u;
+                    e[j] = (x[j] & HM) | ((x[j] >> 8) & ~HM);   // one v_bfi: the tail moves down over the eight bucket bits
+                } else {
+                    e[j] = (x[j] & LMASK) | ((x[j] >> 4) & ~LMASK);  // one v_bfi: base p+1 moves down over the four bucket bits (garbage above it)
+                }
             }
             uint32_t a0, a1, a2, a3;
             unsigned long long m0, m1, m2, m3, k0, k1, k2, k3;
@@ -1838,10 +1890,75 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             else atomicAdd(&hist_s[code], 1u);  // a third single of this lane in one piece (reads full of N)
             ++npend;
         };
+        // ---- quad route: the workgroup's drain points ----
+        // LDS operations of this wave complete (lgkmcnt) before it arrives; vector memory is not waited for.
+        auto wg_sync = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // One drain point: every append issued before it is in the queues (first barrier), every wave moves the full
+        // blocks of its sixteen queues to the arena, and nobody appends again before the queues are set up (second).
+        auto mid_sync = [&]() __attribute__((always_inline)) {
+            wg_sync();
+#ifndef VK_QUAD_MID_DRAIN_AT
+#define VK_QUAD_MID_DRAIN_AT (2 * kBlockBytes)   // inside a step only queues that are filling up fast are drained (skewed bases)
+#endif
+            maybe_drain(VK_QUAD_MID_DRAIN_AT);
+            wg_sync();
+        };
+        // The first drain point of a step (= one piece of every wave that still has pieces): the waves also agree on the
+        // number of drain points of the step, the largest number of append rounds any of them has (at least one).
+        uint32_t qstep = 0;
+        auto step_sync = [&](uint32_t rounds) __attribute__((always_inline)) -> uint32_t {
+            uint32_t* const slots = reinterpret_cast<uint32_t*>(ldsb + kLdsSync);
+            if (lane == 0 && rounds > 1u) atomicMax(&slots[qstep & 1u], rounds);
+            wg_sync();
+            maybe_drain(kBlockBytes);
+            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
+            if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
+            wg_sync();
+            ++qstep;
+            return m > 1u ? m : 1u;
+        };
+        // Quads of which only some windows count wait in two registers per lane, like the singles of the pair route,
+        // and go to the wave's list in HBM at the start of the next piece (one buffer store per lane and register).
+        uint32_t ppend0 = 0, ppend1 = 0, nppend = 0, nmisc = 0;
+        uint32_t* const mlist = QUAD ? bp.misc + (static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)) * bp.misc_cap : nullptr;
+        auto partial = [&](uint32_t entry) __attribute__((always_inline)) {   // K + 3 bases | OK bits << 24
+            if (nppend == 0u) ppend0 = entry;
+            else if (nppend == 1u) ppend1 = entry;
+            else count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);   // a third one of this lane in one piece
+            ++nppend;
+        };
+        auto flush_partials = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 2; ++i) {
+                const bool have = nppend > i;
+                const unsigned long long bal = __ballot(have);
+                if (bal != 0ull) {
+                    const uint32_t entry = i == 0 ? ppend0 : ppend1;
+                    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(bal));
+                    if (nmisc + n > bp.misc_cap) {   // the list is full (reads riddled with N): exact, slow
+                        if (have) count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);
+                    } else {
+                        if (have) {
+                            const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(mlist, 0, static_cast<int>(bp.misc_cap * 4u), 0x00020000);
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bal >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u));
+                            __builtin_amdgcn_raw_buffer_store_b32(entry, mrsrc, (nmisc + rank) * 4u, 0, 0);
+                        }
+                        nmisc = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(nmisc + n)));
+                    }
+                }
+            }
+            nppend = 0u;
+        };
 #ifdef VK_DIAG_K9_BARRIER   // timing only: what two workgroup barriers per piece cost
         uint32_t diag_piece = 0;
 #endif
         auto piece_start = [&](const uint4&) __attribute__((always_inline)) {
+            if constexpr (QUAD) {
+                flush_partials();   // (the queues are drained at the step's first drain point, in `win`)
+                return;
+            }
 #ifdef VK_DIAG_K9_BARRIER
             if (diag_piece < diag_nbar) {
                 __builtin_amdgcn_s_barrier();
@@ -1912,6 +2029,41 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 }
             }
         };
+        // The quad route's append stage of one lane group: its four quads (windows ending at 4j .. 4j + 3).
+        auto append_quads = [&](uint32_t lo, uint32_t hi, uint32_t okg) __attribute__((always_inline)) {
+            // bit 8j of `all` / `some`: all four / some but not all of the windows ending at 4j .. 4j + 3 count
+            const uint32_t p2 = okg & (okg >> 2), o2 = okg | (okg >> 2);
+            const uint32_t all = p2 & (p2 >> 4) & 0x01010101u;
+            const uint32_t some = ((o2 | (o2 >> 4)) & 0x01010101u) ^ all;
+            uint32_t x[4], f[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = 32 + 2 * (4 * j - K + 1);      // bit offset of the quad's first base in [lo | hi]
+                x[j] = o >= 32 ? (hi >> (o - 32)) : vkl::alignbit(hi, lo, static_cast<uint32_t>(o));
+                f[j] = all & (1u << (8 * j));
+            }
+            const uint32_t full = append4(x, f);
+            if (__any(full != 0u)) hot = true;
+            if (full) {  // rare: the queue was full, count the quad directly
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (full & (1u << j)) count_quad_direct<K>(hist_s, x[j], 0x55u);
+            }
+#ifdef VK_DIAG_QUAD_NO_PARTIAL   // timing only
+            uint32_t rem = 0u & some;
+#else
+            uint32_t rem = some;
+#endif
+            while (__any(rem != 0u)) {   // ~1.5 per read: a round or two per call
+                if (rem != 0u) {
+                    const uint32_t b = vkl::ffbl(rem);                 // 8j
+                    rem &= rem - 1u;
+                    const uint32_t o = 32u + b - 2u * (K - 1);          // bit offset of the quad's first base in [lo | hi]
+                    const uint32_t xq = (o < 32u ? vkl::alignbit(hi, lo, o) : (hi >> (o - 32u))) & ((1u << (2 * K + 6)) - 1u);
+                    partial(xq | (((okg >> b) & 0x55u) << 24));
+                }
+            }
+        };
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok_) __attribute__((always_inline)) {
             const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
             uint32_t okl[4] = {ok_[0], ok_[1], ok_[2], ok_[3]};
@@ -1964,6 +2116,9 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 }
                 uint2* const xg = reinterpret_cast<uint2*>(ldsb + kLdsXchg) + static_cast<uint32_t>(wave) * 64u;
                 const uint32_t rounds = tot >> 6;
+                // quad route: the step's first drain point; `synced` of its `m` drain points are behind this wave
+                uint32_t m = 0, synced = 1;
+                if constexpr (QUAD) m = step_sync(rounds);
                 for (uint32_t r = 0; r <= rounds; ++r) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
@@ -1974,6 +2129,14 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                     const uint2 e = xg[lz];
                     const uint32_t lo = wave_prev_lane(e.x, xctx);
                     xctx = lane_bcast(e.x, 63);
+                    if constexpr (QUAD) {
+                        append_quads(lo, e.x, e.y);
+                        if (synced < m) {   // a drain point before every further round of the step
+                            mid_sync();
+                            ++synced;
+                        }
+                        continue;
+                    }
 #ifdef VK_DIAG_K9_NO_APPEND
                     asm volatile("" :: "v"(lo), "v"(e.x), "v"(e.y));
 #else
@@ -1986,6 +2149,12 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
 #else
                     maybe_drain(drain_at);
 #endif
+                }
+                if constexpr (QUAD) {
+                    while (synced < m) {   // the drain points of rounds other waves have and this one has not
+                        mid_sync();
+                        ++synced;
+                    }
                 }
                 xpend = tot & 63u;
             }
@@ -2036,19 +2205,41 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 win(ch, C, ok);
             }
         } else {
-            wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
-                                                    piece_start, ph_start, ph_end, sw);
+            if (!QUAD || !wr.empty)
+                wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
+                                                        piece_start, ph_start, ph_end, sw);
         }
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 0 || QUAD) {
             if (xpend != 0u) {  // the groups still waiting in the exchange buffer
                 const uint2* const xg = reinterpret_cast<const uint2*>(ldsb + kLdsXchg) + static_cast<uint32_t>(wave) * 64u;
                 uint2 e = make_uint2(0u, 0u);
                 if (static_cast<uint32_t>(lane) < xpend) e = xg[lane];
                 const uint32_t lo = wave_prev_lane(e.x, xctx);
-                append_group(lo, e.x, e.y);
+                if constexpr (QUAD) append_quads(lo, e.x, e.y);
+                else append_group(lo, e.x, e.y);
                 xpend = 0u;
             }
+        }
+        if constexpr (QUAD) {
+            flush_partials();
+            if (lane == 0) bp.misc_n[static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)] = nmisc;
+            // the steps of the waves that have more pieces than this one (wave_stream's piece count: one `win` per piece),
+            // then one more barrier: the appends behind the last step's drain points are in the queues
+            uint32_t nmax = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                const WaveRange r = wave_range(len, parts, part, w);
+                if (!r.empty) {
+                    const uint64_t o0 = r.w0 != 0 ? r.w0 - 64 : 0;
+                    const uint32_t np = static_cast<uint32_t>((r.w1 - o0 + kPiece - 1) / kPiece);
+                    nmax = np > nmax ? np : nmax;
+                }
+            }
+            while (qstep < nmax) {
+                const uint32_t m = step_sync(0u);
+                for (uint32_t r = 1; r < m; ++r) mid_sync();
+            }
+            wg_sync();
         }
         if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
         if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
@@ -2059,11 +2250,15 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         drain_all(n, n / kBlockBytes);
         n = qcnt[q];
         const uint16_t* q16 = reinterpret_cast<const uint16_t*>(qdata);
-        for (uint32_t i = sub; i < n / 2u; i += 4u) count_entry_direct<K>(hist_s, q, q16[i]);
+        const uint32_t bq = QUAD ? static_cast<uint32_t>(wave) * kQueues + q : q;
+        for (uint32_t i = sub; i < n / 2u; i += 4u) {
+            if constexpr (QUAD) count_quad_direct<K>(hist_s, quad_bases<K>(bq, q16[i]), 0x55u);
+            else count_entry_direct<K>(hist_s, q, q16[i]);
+        }
         const uint32_t used = qused[q];
         if (sub == 0 && used <= kRunBlocks && used != 0u) {
-            hdrs[qrun[q]] = 0x80000000u | (used << 8) | q;
-            atomicAdd(&bp.bsize[s * kQueues + q], used);
+            hdrs[qrun[q]] = 0x80000000u | (used << 8) | bq;
+            if constexpr (!QUAD) atomicAdd(&bp.bsize[s * kQueues + q], used);
         }
     }
     if constexpr (!STREAM) {   // (MODE 2: vk_pack_kernel has written the waves' phase words)
@@ -2343,6 +2538,165 @@ __global__ __launch_bounds__(256) void vk_bucket_merge_kernel(BucketParams bp, u
         const uint4 v = *reinterpret_cast<const uint4*>(bh + q1 * BINS + ((head << 2) | ((lastb & 1u) << LB)));
         const uint32_t sh = (lastb >> 1) * 16u;
         add += ((v.x >> sh) & 0xFFFFu) + ((v.y >> sh) & 0xFFFFu) + ((v.z >> sh) & 0xFFFFu) + ((v.w >> sh) & 0xFFFFu);
+    }
+    uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
+    out[code] += add;
+}
+
+// ---- the quad route behind pass A ------------------------------------------------------------------------
+// vk_quad_list_kernel: one workgroup per sample sorts the sample's closed runs by bucket (a counting sort over
+// the run headers): qfirst[s][b] .. qfirst[s][b + 1] are bucket b's entries of qlist[s], each run | filled blocks << 24.
+__global__ __launch_bounds__(1024) void vk_quad_list_kernel(BucketParams bp) {
+    __shared__ uint32_t cnt[kQuadBuckets], pos[kQuadBuckets];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    if (tid < kQuadBuckets) cnt[tid] = 0u;
+    __syncthreads();
+    uint32_t nruns = bp.cursors[s];
+    if (nruns > bp.runs_cap) nruns = bp.runs_cap;
+    const uint32_t* hdrs = bp.hdrs + static_cast<uint64_t>(s) * bp.runs_cap;
+    for (uint32_t r = tid; r < nruns; r += 1024) {
+        const uint32_t h = hdrs[r];
+        if (h >> 31) atomicAdd(&cnt[h & 0xFFu], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the 256 buckets: four per lane of one wavefront
+        const uint32_t c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+        const uint32_t sum = c0 + c1 + c2 + c3;
+        const uint32_t before = wave_inclusive_sum(sum) - sum;
+        pos[4 * tid] = before;
+        pos[4 * tid + 1] = before + c0;
+        pos[4 * tid + 2] = before + c0 + c1;
+        pos[4 * tid + 3] = before + c0 + c1 + c2;
+        uint32_t* first = bp.qfirst + static_cast<uint64_t>(s) * (kQuadBuckets + 1);
+        first[4 * tid] = before;
+        first[4 * tid + 1] = before + c0;
+        first[4 * tid + 2] = before + c0 + c1;
+        first[4 * tid + 3] = before + c0 + c1 + c2;
+        if (tid == 63) first[kQuadBuckets] = before + sum;
+    }
+    __syncthreads();
+    uint32_t* list = bp.qlist + static_cast<uint64_t>(s) * bp.runs_cap;
+    for (uint32_t r = tid; r < nruns; r += 1024) {
+        const uint32_t h = hdrs[r];
+        if (h >> 31) list[atomicAdd(&pos[h & 0xFFu], 1u)] = r | (((h >> 8) & 0x7Fu) << 24);
+    }
+}
+
+// Pass B of the quad route: one 256-thread workgroup per (sample, bucket) replays the bucket's runs into two u32
+// tables of 4^(K-3) counters in LDS -- an entry's low 2K - 6 bits name its windows 0 and 1 (head, first tail base),
+// its bits [4, 2K - 2) its windows 2 and 3 (head without its first two bases, all three tail bases) -- and stores
+// them to bucket_hist[sample][bucket][2][4^(K-3)].  u32 counters: nothing can wrap, no second replay.
+// The first `nmisc_wgs` workgroups of the launch instead count the quads that pass A listed window by window (four
+// wavefront lists per workgroup): their global atomics run beside the replay.
+template <int K>
+__global__ __launch_bounds__(256) void vk_quad_count_kernel(BucketParams bp, uint32_t* __restrict__ hist_out, uint32_t nmisc_wgs, uint32_t nlists,
+                                                            uint32_t lists_per_sample) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t TB = 1u << (2 * K - 6);            // counters per table
+    constexpr uint32_t M = (TB - 1u) << 2;                // byte offset mask
+    __shared__ uint32_t tab[2 * TB];
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x < nmisc_wgs) {
+        const uint32_t li = blockIdx.x * 4u + (tid >> 6);   // the list = a wavefront of pass A's launch
+        if (li >= nlists) return;
+        // (pass A's grid: unit = sample * parts + part; lists per sample = parts * kWaves)
+        const uint32_t n = bp.misc_n[li];
+        const uint32_t* list = bp.misc + static_cast<uint64_t>(li) * bp.misc_cap;
+        const uint32_t s = li / lists_per_sample;
+        uint32_t* hist_s = hist_out + static_cast<uint64_t>(s) * NCODE;
+        for (uint32_t i = tid & 63u; i < n; i += 64u) {
+            const uint32_t e = list[i];
+            count_quad_direct<K>(hist_s, e & 0xFFFFFFu, e >> 24);
+        }
+        return;
+    }
+    const uint32_t job = blockIdx.x - nmisc_wgs;
+    const uint32_t s = job / kQuadBuckets, q = job % kQuadBuckets;
+    for (uint32_t i = tid; i < 2 * TB; i += 256) tab[i] = 0u;
+    __syncthreads();
+    const uint32_t* first = bp.qfirst + static_cast<uint64_t>(s) * (kQuadBuckets + 1);
+    const uint32_t beg = first[q], end = first[q + 1];
+    const uint32_t* list = bp.qlist + static_cast<uint64_t>(s) * bp.runs_cap;
+    const uint8_t* arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
+    uint8_t* const t0 = reinterpret_cast<uint8_t*>(tab);
+    uint8_t* const t1 = reinterpret_cast<uint8_t*>(tab + TB);
+    auto tally2 = [&](uint32_t w) __attribute__((always_inline)) {  // two entries: the halves of a dword
+        atomicAdd(reinterpret_cast<uint32_t*>(t0 + ((w << 2) & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(t1 + ((w >> 2) & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(t0 + ((w >> 14) & M)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t*>(t1 + ((w >> 18) & M)), 1u);
+    };
+    auto tally4 = [&](const uint4& v) __attribute__((always_inline)) {
+        tally2(v.x);
+        tally2(v.y);
+        tally2(v.z);
+        tally2(v.w);
+    };
+    // every thread reads granule g of a run (a run = 256 granules of 16 bytes: the whole workgroup per run), four
+    // runs in flight
+    auto fetch = [&](uint32_t i, uint4& v) __attribute__((always_inline)) -> bool {
+        const uint32_t item = i < end ? list[i] : 0u;
+        const bool have = i < end && (tid >> 2) < (item >> 24);
+        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + tid);
+        return have;
+    };
+    uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+    bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
+    uint32_t i = beg;
+    ha0 = fetch(i, a0); ha1 = fetch(i + 1, a1); ha2 = fetch(i + 2, a2); ha3 = fetch(i + 3, a3);
+    while (i < end) {
+        hb0 = fetch(i + 4, b0); hb1 = fetch(i + 5, b1); hb2 = fetch(i + 6, b2); hb3 = fetch(i + 7, b3);
+        if (ha0) tally4(a0);
+        if (ha1) tally4(a1);
+        if (ha2) tally4(a2);
+        if (ha3) tally4(a3);
+        i += 4;
+        if (i >= end) break;
+        ha0 = fetch(i + 4, a0); ha1 = fetch(i + 5, a1); ha2 = fetch(i + 6, a2); ha3 = fetch(i + 7, a3);
+        if (hb0) tally4(b0);
+        if (hb1) tally4(b1);
+        if (hb2) tally4(b2);
+        if (hb3) tally4(b3);
+        i += 4;
+    }
+    __syncthreads();
+    uint32_t* out = bp.bucket_hist + (static_cast<uint64_t>(s) * kQuadBuckets + q) * (2 * TB);
+    for (uint32_t j = tid; j < 2 * TB; j += 256) out[j] = tab[j];
+}
+
+// Pass C of the quad route: one thread per k-mer code adds the sixteen counters that can name it -- as window t = 0 .. 3
+// of a quad: four counters each (the base of the pair that the window does not hold is any of four) -- to the histogram,
+// which already holds pass A's direct counts and the listed quads'.  raw = the code with its first base lowest.
+template <int K>
+__global__ __launch_bounds__(256) void vk_quad_merge_kernel(BucketParams bp, uint32_t* __restrict__ hist_out) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr uint32_t TB = 1u << (2 * K - 6);
+    constexpr uint32_t HB = 2 * K - 8;                    // bits of an entry's head
+    const uint32_t s = blockIdx.x / (NCODE / 256), code = (blockIdx.x % (NCODE / 256)) * 256 + threadIdx.x;
+    const uint32_t raw = pair_reverse(code, K);
+    const uint32_t* bh = bp.bucket_hist + static_cast<uint64_t>(s) * kQuadBuckets * (2 * TB);
+    uint32_t add = 0;
+    {   // t = 0: bases b0 .. b(K-1): head = the first K - 4, bucket = the last four; the first tail base is any
+        const uint32_t q = raw >> HB, head = raw & ((1u << HB) - 1u);
+        const uint32_t* t = bh + static_cast<uint64_t>(q) * (2 * TB);
+#pragma unroll
+        for (uint32_t a = 0; a < 4; ++a) add += t[head | (a << HB)];
+    }
+    {   // t = 1: bases b1 .. b(K): b0 is any (the index's lowest two bits: one 16-byte load)
+        const uint32_t q = (raw >> (HB - 2)) & 0xFFu, head1 = raw & ((1u << (HB - 2)) - 1u), tail0 = raw >> (2 * K - 2);
+        const uint4 v = *reinterpret_cast<const uint4*>(bh + static_cast<uint64_t>(q) * (2 * TB) + ((head1 << 2) | (tail0 << HB)));
+        add += v.x + v.y + v.z + v.w;
+    }
+    {   // t = 2: bases b2 .. b(K+1): second table, index = (b2 .. b(K-5)) | tail << (2K - 12); the third tail base is any
+        const uint32_t q = (raw >> (HB - 4)) & 0xFFu, head2 = raw & ((1u << (HB - 4)) - 1u), tail01 = raw >> (2 * K - 4);
+        const uint32_t* t = bh + static_cast<uint64_t>(q) * (2 * TB) + TB;
+#pragma unroll
+        for (uint32_t a = 0; a < 4; ++a) add += t[head2 | (tail01 << (HB - 4)) | (a << HB)];
+    }
+    {   // t = 3: bases b3 .. b(K+2): b2 is any (lowest two bits of the index)
+        const uint32_t q = (raw >> (HB - 6)) & 0xFFu, head3 = raw & ((1u << (HB - 6)) - 1u), tail = raw >> (2 * K - 6);
+        const uint4 v = *reinterpret_cast<const uint4*>(bh + static_cast<uint64_t>(q) * (2 * TB) + TB + ((head3 << 2) | (tail << (HB - 4))));
+        add += v.x + v.y + v.z + v.w;
     }
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
     out[code] += add;

@@ -114,6 +114,7 @@ struct vk_ctx {
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
     bool spill_packed = false;     // VKIMG_SPILL_PACKED=1: k = 8, 9 pass A in two kernels, vk_pack_kernel + the partition of the packed stream (measured slower than the one kernel that classifies every byte: 21.1 against 16.3 ms per 100 samples; tests, A/B timing)
+    bool spill_pairs = true;       // VKIMG_SPILL_QUADS=1 clears it: k = 8, 9 through the quad route (u16 per four windows, workgroup-shared queues) instead of the pair route of rounds 1-4
     bool spill_force_wide = false; // VKIMG_SPILL_FORCE_WIDE=1: every k = 8, 9 replay job through the u32 window counters (tests)
     bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
 };
@@ -235,11 +236,92 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     return VK_OK;
 }
 
+// k = 8, 9, the quad route (vk_count.h: vk_bucket_kernel<K, 3>, vk_quad_list / _count / _merge_kernel), in sub-batches
+// that fit the spill budget.
+template <int K>
+int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
+                      uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist) {
+    constexpr uint32_t NCODE = 1u << (2 * K);
+    constexpr size_t kTableWords = 2u << (2 * K - 6);   // the two tables of one bucket
+    // Arena of one sample, in 4 KiB runs: a quad entry is 2 bytes and a FASTQ holds at most len / 8 quads (sequence
+    // lines are less than half of the text), so len / 4 bytes however they spread over the 256 buckets; plus the
+    // blocks a drain may leave unused at the end of a run, one open run per (workgroup, queue), one reserve per wave.
+    uint64_t runs = (maxlen / 4 + maxlen / 32) / kRunBytes + 16 + static_cast<uint64_t>(parts) * (kQuadBuckets + kWaves * kPoolRuns);
+    if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
+    if (runs >= (1u << 24)) return VK_EINVAL;
+    // the waves' lists of quads counted window by window: ~19 per 4 KiB piece of 150-base reads; room for one per 32 bytes
+    const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
+    uint64_t mcap = wave_bytes / 32 + 64;
+    if (mcap > (1u << 24)) mcap = 1u << 24;
+    const size_t lists = static_cast<size_t>(parts) * kWaves;   // per sample
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (kQuadBuckets + 2) * sizeof(uint32_t) +
+                              kQuadBuckets * kTableWords * sizeof(uint32_t) + lists * (mcap + 1) * sizeof(uint32_t) + 64;
+    size_t free_b = 0, total_b = 0;
+    VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = ctx->spill_budget;
+    const size_t avail = free_b / 4 * 3 + ctx->spill_cap;
+    if (budget > avail) budget = avail;
+    uint32_t batch = static_cast<uint32_t>(budget / per_sample);
+    if (batch == 0) batch = 1;
+    if (batch > nsamples) batch = nsamples;
+    // workspace: cursors[batch] | hdrs[batch][runs] (zeroed per sub-batch) | qfirst[batch][257] | qlist[batch][runs] |
+    //            misc_n[batch * lists] | misc[batch * lists][mcap] | bucket tables[batch][256][2][4^(K-3)] | arena[batch][runs][4 KiB]
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t head_bytes = up(static_cast<size_t>(batch) * (1 + runs) * sizeof(uint32_t));
+    const size_t list_bytes = up(static_cast<size_t>(batch) * (kQuadBuckets + 1 + runs) * sizeof(uint32_t));
+    const size_t misc_bytes = up(static_cast<size_t>(batch) * lists * (mcap + 1) * sizeof(uint32_t));
+    const size_t bh_bytes = static_cast<size_t>(batch) * kQuadBuckets * kTableWords * sizeof(uint32_t);
+    const size_t arena_bytes = static_cast<size_t>(batch) * runs * kRunBytes;
+    int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap, head_bytes + list_bytes + misc_bytes + bh_bytes + arena_bytes);
+    if (rc) return rc;
+    uint8_t* const base = reinterpret_cast<uint8_t*>(ctx->d_spill);
+    BucketParams bp{};
+    bp.cursors = ctx->d_spill;
+    bp.hdrs = ctx->d_spill + batch;
+    bp.qfirst = reinterpret_cast<uint32_t*>(base + head_bytes);
+    bp.qlist = bp.qfirst + static_cast<size_t>(batch) * (kQuadBuckets + 1);
+    bp.misc_n = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes);
+    bp.misc = bp.misc_n + static_cast<size_t>(batch) * lists;
+    bp.misc_cap = static_cast<uint32_t>(mcap);
+    bp.bucket_hist = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes + misc_bytes);
+    bp.arena = base + head_bytes + list_bytes + misc_bytes + bh_bytes;
+    bp.runs_cap = static_cast<uint32_t>(runs);
+    VK_HIP(ctx, hipMemsetAsync(d_hist, 0, static_cast<size_t>(nsamples) * NCODE * sizeof(uint32_t), ctx->stream));
+    ctx->last_block = kCountThreads;
+    ctx->last_lds = kLdsBucketBytes;
+    for (uint32_t s0 = 0; s0 < nsamples; s0 += batch) {
+        const uint32_t n = nsamples - s0 < batch ? nsamples - s0 : batch;
+        VK_HIP(ctx, hipMemsetAsync(ctx->d_spill, 0, head_bytes, ctx->stream));  // cursors and run headers
+        ctx->last_grid = n * parts;
+        uint32_t* const hist0 = d_hist + static_cast<size_t>(s0) * NCODE;
+        uint32_t* const wph0 = ctx->d_wavephase + static_cast<size_t>(s0) * parts * kWaves;
+        hipLaunchKernelGGL((vk_bucket_kernel<K, 3>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
+                           d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, PackParams{});
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(vk_quad_list_kernel, dim3(n), dim3(1024), 0, ctx->stream, bp);
+        VK_HIP(ctx, hipGetLastError());
+        const uint32_t nlists = n * static_cast<uint32_t>(lists);
+#ifdef VK_DIAG_QUAD_NO_MISC   // timing only
+        const uint32_t nmisc_wgs = 0;
+#else
+        const uint32_t nmisc_wgs = (nlists + 3) / 4;
+#endif
+        hipLaunchKernelGGL((vk_quad_count_kernel<K>), dim3(nmisc_wgs + n * kQuadBuckets), dim3(256), 0, ctx->stream, bp, hist0,
+                           nmisc_wgs, nlists, static_cast<uint32_t>(lists));
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL((vk_quad_merge_kernel<K>), dim3(n * (NCODE / 256)), dim3(256), 0, ctx->stream, bp, hist0);
+        VK_HIP(ctx, hipGetLastError());
+    }
+    return VK_OK;
+}
+
 // k = 8, 9: bucket pass + replay pass, in sub-batches that fit the spill budget.
 template <int K>
 int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
                  uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist, const SubParams* sub) {
     constexpr uint32_t NCODE = 1u << (2 * K);
+    if (sub == nullptr && !ctx->spill_packed && !ctx->spill_pairs)
+        return launch_spill_quad<K>(ctx, d_fastq, d_offs, d_lens, nsamples, parts, maxlen, d_hist);
     // Arena of one sample, in 4 KiB runs: a pair entry is 2 bytes and a FASTQ holds at most len / 4
     // pairs (sequence lines are less than half of the text), so len / 2 bytes however the pairs spread
     // over the 16 buckets; plus the blocks a drain may leave unused at the end of a run (at most 3 of
@@ -417,6 +499,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
         const char* tf = getenv("VKIMG_SPILL_PACKED");
         ctx->spill_packed = tf && tf[0] == '1';
+        const char* sq = getenv("VKIMG_SPILL_QUADS");
+        ctx->spill_pairs = !(sq && sq[0] == '1');
         const char* fw = getenv("VKIMG_SPILL_FORCE_WIDE");
         ctx->spill_force_wide = fw && fw[0] == '1';
         const char* kc = getenv("VKIMG_K1_CLASSIC");

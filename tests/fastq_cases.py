@@ -38,6 +38,21 @@ def edge_cases():
     return cases
 
 
+LARGE_CASES = ("long_read", "many_short", "ragged", "exact_64_multiple")
+
+
+def dsk_kit_cases(k):
+    """The cases of the dsk closing kit at k (oracle/gen_golden_dsktext.py): all of edge_cases() at k = 7; at the
+    other k the hand-written ones, with `len_k` / `len_k_minus_1` re-made for that k."""
+    cases = edge_cases()
+    if k != 7:
+        for name in LARGE_CASES:
+            del cases[name]
+        cases["len_k"] = rec("r", "ACGTACGTAC"[:k])
+        cases["len_k_minus_1"] = rec("r", "ACGTACGTAC"[:k - 1])
+    return cases
+
+
 def random_fastq(rng, nrec=None):
     """A structurally valid 4-line FASTQ with adversarial content: zero-length and very long reads,
     IUPAC / lower-case / punctuation in sequences, '@' and '+' leading quality lines, long or empty

@@ -99,6 +99,34 @@ def test_subfolder_levels_and_errors(tmp_path):
         image.count_kmers(bad, tmp_path / "c", k=5)
 
 
+def test_count_kmers_takes_an_empty_text_gz_and_rejects_a_damaged_one(tmp_path):
+    """The function entry and the dsk shim (tests/test_shims.py) agree on the same inputs: a valid .gz whose text is
+    empty is a sample without k-mers -- dsk exits 0 on it, so `check=True` passes (commands/image.py:791-796), and the
+    empty dsk2ascii dump only fails later, in make_image's read_csv (:897-899) -- while a damaged .gz makes dsk fail."""
+    import gzip
+    import pandas as pd
+    k = 7
+    empty = tmp_path / "E@00000001K.fq.gz"
+    empty.write_bytes(gzip.compress(b""))
+    st = image.count_kmers(empty, tmp_path / "c", k=k)
+    assert list(st.keys()) == [f"{k}mer_counting_time"]
+    kk, hist = image.read_counts(tmp_path / "c" / f"E@00000001K+k{k}.fq.h5")
+    assert kk == k and not hist.any()
+    with pytest.raises(pd.errors.EmptyDataError):       # the reference's IMAGE FAIL path (image.py:1111-1118 catches ParserError's family)
+        image.make_image(tmp_path / "c" / f"E@00000001K+k{k}.fq.h5", tmp_path / "i", get_kmer_mapping(k, "cgr"), mapping_code="cgr")
+    data = synth.sample_fastq(3, 2000, 150, dist=1).tobytes()
+    blob = bytearray(gzip.compress(data))
+    blob[len(blob) // 2] ^= 0xFF
+    bad = tmp_path / "B@00000001K.fq.gz"
+    bad.write_bytes(bytes(blob))
+    with pytest.raises(RuntimeError, match="not a readable"):
+        image.count_kmers(bad, tmp_path / "c", k=k)
+    assert not (tmp_path / "c" / f"B@00000001K+k{k}.fq.h5").exists()
+    empty_plain = tmp_path / "P@00000001K.fq"            # a zero-byte plain file: the same empty table
+    empty_plain.write_bytes(b"")
+    assert list(image.count_kmers(empty_plain, tmp_path / "c", k=k).keys()) == [f"{k}mer_counting_time"]
+
+
 def test_batched_pipeline_writes_reference_named_pngs(tmp_path):
     """pipeline.fastqs_to_images: many split FASTQs per launch, PNGs + stats keys as steps D+E
     of run_clean2img (image.py:1054-1127); pixels equal the oracle's."""

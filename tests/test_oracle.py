@@ -131,21 +131,33 @@ SYNTH_SHA0 = "d3e00ad16ca1838a"
 SYNTH_SHA1 = "c75101c30b4a16db"
 
 
-def test_edge_case_dsk_text_goldens_are_current():
-    """tests/golden/dsk_text_k7/*.txt (oracle/gen_golden_dsktext.py): the dsk2ascii-style dump of every
-    edge case as this build counts it -- kept so that a machine with GATB dsk 2.3.3 can close the
-    'counting parity unpinned' gap with one diff per case."""
+@pytest.mark.parametrize("k", [5, 6, 7, 8, 9])
+def test_edge_case_dsk_text_goldens_are_current(k):
+    """tests/golden/dsk_text_k<k>/*.txt (oracle/gen_golden_dsktext.py): the dsk2ascii-style dump of every
+    edge case as this build counts it, for every k the package claims -- kept so that a machine with GATB
+    dsk 2.3.3 can close the 'counting parity unpinned' gap with one diff per case."""
     import os
 
-    from fastq_cases import edge_cases
+    from fastq_cases import dsk_kit_cases
     from varkoder_amd import formats
-    gold = os.path.join(os.path.dirname(__file__), "golden", "dsk_text_k7")
-    for name, fq in edge_cases().items():
-        hist, _, st = oracle.count_fastq(fq, 7)
+    gold = os.path.join(os.path.dirname(__file__), "golden", f"dsk_text_k{k}")
+    cases = dsk_kit_cases(k)
+    assert {f[:-4] for f in os.listdir(gold) if f.endswith(".txt")} == set(cases)
+    for name, fq in cases.items():
+        hist, nwin, st = oracle.count_fastq(fq, k)
         assert st == 0
+        text = formats.dsk_text(hist, k, "gatb")
         with open(os.path.join(gold, name + ".txt")) as f:
-            assert f.read() == formats.dsk_text(hist, 7, "gatb"), name
+            assert f.read() == text, name
+        # the dump is canonical: every class once, under its GATB spelling, counts summing to the windows
+        assert sum(int(line.split()[1]) for line in text.splitlines()) == nwin
         p = os.path.join(gold, name + ".fq")
         if os.path.exists(p):
             with open(p, "rb") as f:
                 assert f.read() == fq, name
+    if k in (6, 8):   # even k: the palindrome case really holds palindromes, each dumped once with its full count
+        hist = oracle.count_fastq(cases["palindromes_even_k"], k)[0]
+        from varkoder_amd.mapping import revcomp_codes
+        nz = np.nonzero(hist)[0]
+        pal = nz[revcomp_codes(k)[nz] == nz]
+        assert len(pal), "no palindromic k-mer in the palindrome case"

@@ -73,6 +73,51 @@ def test_two_rank_gloo_sharding_covers_every_sample_once():
         assert got["rank"] == s % world
 
 
+LADDERS = {6: [500, 1000, 2000, 5000, 10000, 20000], 8: [500, 1000, 2000, 5000, 10000, 20000, 50000, 100000],
+           9: [500, 1000, 2000, 5000, 10000, 20000, 50000, 100000, 200000]}   # Kbp per rung (commands/image.py:682-695)
+
+
+@pytest.mark.parametrize("rungs", [6, 8, 9])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_size_aware_shard_balances_the_reference_ladder(rungs, world):
+    """`split_fastqs/` of 100 samples: one file per rung and sample, sorted by name = by size within a sample
+    (commands/image.py:682-708).  i % world pins rungs to ranks (8 rungs on 8 ranks: one rank gets every 100M
+    file); shard_by_size keeps every rank within 5 % of the mean and still covers every file exactly once."""
+    from varkoder_amd import shard
+    names = sorted(f"s{s:03d}@{kbp:08d}K.fq" for s in range(100) for kbp in LADDERS[rungs])
+    weights = [int(n.split("@")[1][:8]) * 2133 for n in names]   # ~2.13 bytes of FASTQ per base
+    loads = shard.rank_loads(weights, world)
+    assert max(loads) / (sum(loads) / world) <= 1.05
+    parts = [shard.shard_by_size(weights, r, world) for r in range(world)]
+    assert sorted(i for p in parts for i in p) == list(range(len(names)))
+    assert all(p == sorted(p) for p in parts)
+    # what the static round-robin did with the same list (the verdict's numbers: 1.48x of 2 at world 2 on six rungs)
+    rr = [sum(weights[i] for i in shard.shard_indices(len(names), r, world)) for r in range(world)]
+    if rungs % world == 0 or world % rungs == 0:
+        assert max(rr) / (sum(rr) / world) > 1.3
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_size_aware_shard_balances_unsplit_clean_files(world):
+    """--from-clean inputs: one file per sample, sizes spread over two orders of magnitude."""
+    from varkoder_amd import shard
+    rng = np.random.default_rng(11)
+    weights = [int(w) for w in np.exp(rng.normal(18.0, 1.0, size=100))]
+    loads = shard.rank_loads(weights, world)
+    assert max(loads) / (sum(loads) / world) <= 1.05
+    assert shard.shard_by_size(weights, 0, 1) == list(range(100))
+    assert shard.shard_by_size([], 0, world) == []
+    with pytest.raises(ValueError):
+        shard.shard_by_size(weights, world, world)
+
+
+def test_file_weights_count_text_bytes(tmp_path):
+    from varkoder_amd import shard
+    (tmp_path / "a.fq").write_bytes(b"x" * 100)
+    (tmp_path / "b.fq.gz").write_bytes(b"y" * 10)
+    assert shard.file_weights([tmp_path / "a.fq", tmp_path / "b.fq.gz", tmp_path / "missing.fq"]) == [100, 60, 0]
+
+
 def test_single_process_helpers_are_identity():
     from varkoder_amd import shard
     assert shard.max_over_ranks(3.5) == 3.5

@@ -117,7 +117,7 @@ def run_convert(args):
 def run_query(args):
     """`varKoder query` from step C on (commands/query.py:188-324): images are made on the GPU and
     stay there for the model's input transform; predictions.csv has the reference's columns.
-    Under a launcher (one process per GPU) the inputs are sharded round-robin over the ranks -- every rank
+    Under a launcher (one process per GPU) the inputs are sharded by size over the ranks (shard.shard_by_size) -- every rank
     makes its images and runs the model on its GPU -- and rank 0 writes predictions.csv in input order
     (BASELINE config 5: images + batched inference on 8 GPUs; no data-path collective, one object gather)."""
     import numpy as np
@@ -127,7 +127,7 @@ def run_query(args):
     from .convert import get_metadata_from_img_filename
     from .engine import ImageEngine
     from .image import write_png
-    from .shard import shard_indices, world_info
+    from .shard import file_weights, shard_by_size, world_info
     from .subsample import ladder_counts, split_name
     rank, world, device = world_info()
     outdir = Path(args.outdir)
@@ -153,7 +153,7 @@ def run_query(args):
 
     def rank_work():
         nonlocal model, vocab
-        mine = shard_indices(len(inputs), rank, world)
+        mine = shard_by_size(file_weights(inputs), rank, world)
         model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
         records, images, order = [], None, []   # order: index of each record's input in `inputs`
         eng = None

@@ -169,8 +169,11 @@ def count_kmers(infile, outfolder, threads=1, k=7, overwrite=False, verbose=Fals
     # the file crosses PCIe as it is on disk; a .gz is inflated on the GPU (dsk reads .gz natively)
     eng = _engine(k, "count")
     dev, offs, lens = eng.upload_files([infile])
-    if Path(infile).stat().st_size and not int(lens[0]):
-        raise RuntimeError(f"k-mer counting failed for {infile}: not a readable FASTQ / gzip file")
+    # (the inflate's own status, as the dsk shim reads it: a .gz whose TEXT is empty is a valid input -- dsk exits 0 on
+    # it and dsk2ascii dumps nothing, commands/image.py:791-796, :897-899 -- only an unreadable or damaged file fails)
+    if int(eng.last_upload_status[0]):
+        raise RuntimeError(f"k-mer counting failed for {infile}: not a readable FASTQ / gzip file "
+                           f"(status {int(eng.last_upload_status[0])})")
     h, st = eng.count(dev, offs, lens)
     hist, status = h.cpu().numpy().view(np.uint32)[0], int(st.cpu()[0])
     if status:

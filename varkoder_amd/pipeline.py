@@ -14,7 +14,7 @@ from pathlib import Path
 
 from .config import QUAL_THRESH
 from .image import counts_name, eprint, png_name, shard_folder, write_png
-from .shard import shard_indices
+from .shard import file_weights, shard_by_size
 
 
 # Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
@@ -46,7 +46,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     files = [Path(f) for f in files]
     labels = labels or {}
     base_sd = base_sd or {}
-    mine = [files[i] for i in shard_indices(len(files), rank, world)]
+    mine = [files[i] for i in shard_by_size(file_weights(files), rank, world)]   # size-aware: see shard.shard_by_size
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)
@@ -152,7 +152,7 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
     from .subsample import ladder_counts, split_name
     files = [Path(f) for f in files]
     labels, base_sd, seeds = labels or {}, base_sd or {}, seeds or {}
-    mine = [files[i] for i in shard_indices(len(files), rank, world)]
+    mine = [files[i] for i in shard_by_size(file_weights(files), rank, world)]   # size-aware: see shard.shard_by_size
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)

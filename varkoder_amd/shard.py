@@ -54,11 +54,58 @@ def io_threads_per_rank(n_threads):
 
 
 def shard_indices(n_items, rank, world):
-    """Round-robin shard: item i belongs to rank i % world (balanced to within one item,
-    and neighbouring -- similarly sized -- samples land on different GPUs)."""
+    """Round-robin shard for units of EQUAL size (bench.py's synthetic samples): item i belongs to rank
+    i % world, balanced to within one item.  Files are sharded by size instead: shard_by_size."""
     if not (0 <= rank < world):
         raise ValueError("rank out of range")
     return list(range(rank, n_items, world))
+
+
+def shard_by_size(weights, rank, world):
+    """This rank's items (ascending indices) under the longest-processing-time rule: items in order of
+    decreasing weight (ties: lower index first), each to the rank with the least weight so far (ties:
+    lower rank).  Every rank computes the same assignment from the same weights -- no collective, no
+    shared queue -- and no rank carries more than the mean load plus one item.
+
+    Why not i % world: the reference hands samples to whichever pool worker is free
+    (`pool.imap_unordered`, commands/image.py:1281-1284), so sizes do not matter to it; a static
+    round-robin over SORTED file names does not have that property -- `split_fastqs/` holds one file
+    per rung of the 1-2-5 ladder and sample (`<sample>@<bp 8 digits>K`, :682-708), the names sort by
+    size within a sample, and i % world pins rungs to ranks (6 rungs on 2 ranks: 12.5 M against 26 M
+    bases per sample)."""
+    import heapq
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    order = sorted(range(len(weights)), key=lambda i: (-int(weights[i]), i))
+    heap = [(0, r) for r in range(world)]   # (load, rank): heapq pops the least load, then the lowest rank
+    mine = []
+    for i in order:
+        load, r = heapq.heappop(heap)
+        if r == rank:
+            mine.append(i)
+        heapq.heappush(heap, (load + int(weights[i]), r))
+    return sorted(mine)
+
+
+def rank_loads(weights, world):
+    """Total weight of every rank under shard_by_size (tests, bench.py's report)."""
+    return [sum(int(weights[i]) for i in shard_by_size(weights, r, world)) for r in range(world)]
+
+
+GZ_TEXT_RATIO = 6   # text bytes per compressed byte assumed when plain and gzip files meet in one job (pipeline's batching uses the same)
+
+
+def file_weights(files):
+    """Work estimate of each input file: its text bytes (a .gz counts GZ_TEXT_RATIO times its size; a
+    missing file 0 -- it fails later, on the rank that gets it)."""
+    out = []
+    for f in files:
+        try:
+            sz = os.path.getsize(f)
+        except OSError:
+            sz = 0
+        out.append(sz * (GZ_TEXT_RATIO if str(f).endswith(".gz") else 1))
+    return out
 
 
 def max_over_ranks(value, device=None):

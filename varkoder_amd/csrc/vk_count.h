@@ -1562,9 +1562,10 @@ struct BucketParams {
     // the quad route (MODE 3 of vk_bucket_kernel; bsize / order / wide are not used by it):
     uint32_t* qfirst;    // [nsamples][kQuadBuckets + 1] first entry of every bucket's runs in qlist (vk_quad_list_kernel)
     uint32_t* qlist;     // [nsamples][runs_cap] closed runs sorted by bucket: run | filled blocks << 24
-    uint32_t* misc;      // [grid * kWaves][misc_cap] quads of which only some windows count: K + 3 bases | OK bits << 24
-    uint32_t* misc_n;    // [grid * kWaves] entries in each list
-    uint32_t misc_cap;
+    uint32_t* preg;      // [grid][kQuadBuckets][preg_cap] quads of which only some windows count, by pass A workgroup and bucket: K + 3 bases | OK bits << 24
+    uint32_t* preg_n;    // [grid][kQuadBuckets] entries in each region
+    uint32_t preg_cap;
+    uint32_t parts;      // workgroups of pass A per sample
 };
 
 // LDS of the bucket kernel, one array with fixed offsets (the hand-written queue appends address it
@@ -1581,7 +1582,8 @@ constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
 constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
 constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [2]: the quad route's rounds of a step, agreed by the workgroup
-static_assert(kLdsSync + 8 <= kLdsQueues, "LDS layout");
+constexpr uint32_t kLdsCntP = kLdsSync + 8;                       // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
+static_assert(kLdsCntP + 256 * 4 <= kLdsQueues, "LDS layout");
 constexpr uint32_t kQuadBuckets = 256;    // the quad route's bucket streams per sample = kWaves * kQueues queues per WORKGROUP
 static_assert(kQuadBuckets == kWaves * kQueues, "a wave drains sixteen of its workgroup's queues");
 static_assert(2 * kLdsBucketBytes <= 160 * 1024, "two bucket workgroups per CU");  // = exactly 160 KiB
@@ -1684,6 +1686,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
     }
     if (lane < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsPool)[wave * 2 + lane] = 0u;   // an empty reserve
     if (tid < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
+    if (QUAD && tid < static_cast<int>(kQuadBuckets)) reinterpret_cast<uint32_t*>(ldsb + kLdsCntP)[tid] = 0u;
     __syncthreads();
 
     const uint8_t* sbase = fastq + offs[s];
@@ -1919,46 +1922,29 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             ++qstep;
             return m > 1u ? m : 1u;
         };
-        // Quads of which only some windows count wait in two registers per lane, like the singles of the pair route,
-        // and go to the wave's list in HBM at the start of the next piece (one buffer store per lane and register).
-        uint32_t ppend0 = 0, ppend1 = 0, nppend = 0, nmisc = 0;
-        uint32_t* const mlist = QUAD ? bp.misc + (static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)) * bp.misc_cap : nullptr;
-        auto partial = [&](uint32_t entry) __attribute__((always_inline)) {   // K + 3 bases | OK bits << 24
-            if (nppend == 0u) ppend0 = entry;
-            else if (nppend == 1u) ppend1 = entry;
-            else count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);   // a third one of this lane in one piece
-            ++nppend;
-        };
-        auto flush_partials = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (uint32_t i = 0; i < 2; ++i) {
-                const bool have = nppend > i;
-                const unsigned long long bal = __ballot(have);
-                if (bal != 0ull) {
-                    const uint32_t entry = i == 0 ? ppend0 : ppend1;
-                    const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(bal));
-                    if (nmisc + n > bp.misc_cap) {   // the list is full (reads riddled with N): exact, slow
-                        if (have) count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);
-                    } else {
-                        if (have) {
-                            const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(mlist, 0, static_cast<int>(bp.misc_cap * 4u), 0x00020000);
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bal >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal), 0u));
-                            __builtin_amdgcn_raw_buffer_store_b32(entry, mrsrc, (nmisc + rank) * 4u, 0, 0);
-                        }
-                        nmisc = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(nmisc + n)));
-                    }
-                }
+        // Quads of which only some windows count (~1.5 per read) go to HBM as they are found, into the workgroup's region
+        // of their bucket (pass B's job of the bucket reads the regions of the sample's workgroups): the place comes from a
+        // returning LDS atomic on the workgroup's counter of the bucket; a full region: exact, slow.  (The words of a
+        // region are written a few at a time, pieces apart, and meet in L2: 256 open lines per workgroup.)
+        uint32_t* const cntp = reinterpret_cast<uint32_t*>(ldsb + kLdsCntP);
+        uint32_t* const pregion = QUAD ? bp.preg + static_cast<uint64_t>(unit) * kQuadBuckets * bp.preg_cap : nullptr;
+        auto partial = [&](bool have, uint32_t entry) __attribute__((always_inline)) {   // entry: K + 3 bases | OK bits << 24
+            const uint32_t bq = (entry >> (2 * K - 8)) & 0xFFu;
+            uint32_t a = 0xFFFFFFFFu;
+            if (have) a = atomicAdd(&cntp[bq], 1u);
+            if (a < bp.preg_cap) {
+                const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(pregion, 0, static_cast<int>(kQuadBuckets * bp.preg_cap * 4u), 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(entry, prsrc, (bq * bp.preg_cap + a) * 4u, 0, 0);
             }
-            nppend = 0u;
+            if (__any(have && a >= bp.preg_cap)) {
+                if (have && a >= bp.preg_cap) count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);
+            }
         };
 #ifdef VK_DIAG_K9_BARRIER   // timing only: what two workgroup barriers per piece cost
         uint32_t diag_piece = 0;
 #endif
         auto piece_start = [&](const uint4&) __attribute__((always_inline)) {
-            if constexpr (QUAD) {
-                flush_partials();   // (the queues are drained at the step's first drain point, in `win`)
-                return;
-            }
+            if constexpr (QUAD) return;   // (the queues are drained at the step's first drain point, in `win`)
 #ifdef VK_DIAG_K9_BARRIER
             if (diag_piece < diag_nbar) {
                 __builtin_amdgcn_s_barrier();
@@ -2054,13 +2040,19 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
 #else
             uint32_t rem = some;
 #endif
-            while (__any(rem != 0u)) {   // ~1.5 per read: a round or two per call
-                if (rem != 0u) {
-                    const uint32_t b = vkl::ffbl(rem);                 // 8j
+            // the lane's first such quad in straight-line code (most calls find one in some lane, few lanes have two)
+            auto entry_at = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {   // b = 8j
+                const uint32_t o = (32u - 2u * (K - 1) + b) & 63u;   // bit offset of the quad's first base in [lo | hi]
+                const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
+                const uint32_t xq = static_cast<uint32_t>(v >> o) & ((1u << (2 * K + 6)) - 1u);
+                return xq | (((okg >> (b & 31u)) & 0x55u) << 24);
+            };
+            if (__any(rem != 0u)) {
+                partial(rem != 0u, entry_at(vkl::ffbl(rem) & 24u));
+                rem &= rem - 1u;
+                while (__any(rem != 0u)) {   // reads cut up by N, read ends that meet in one group
+                    partial(rem != 0u, entry_at(vkl::ffbl(rem) & 24u));
                     rem &= rem - 1u;
-                    const uint32_t o = 32u + b - 2u * (K - 1);          // bit offset of the quad's first base in [lo | hi]
-                    const uint32_t xq = (o < 32u ? vkl::alignbit(hi, lo, o) : (hi >> (o - 32u))) & ((1u << (2 * K + 6)) - 1u);
-                    partial(xq | (((okg >> b) & 0x55u) << 24));
                 }
             }
         };
@@ -2222,8 +2214,6 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
         }
         if constexpr (QUAD) {
-            flush_partials();
-            if (lane == 0) bp.misc_n[static_cast<uint64_t>(unit) * kWaves + static_cast<uint32_t>(wave)] = nmisc;
             // the steps of the waves that have more pieces than this one (wave_stream's piece count: one `win` per piece),
             // then one more barrier: the appends behind the last step's drain points are in the queues
             uint32_t nmax = 0;
@@ -2240,6 +2230,10 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 for (uint32_t r = 1; r < m; ++r) mid_sync();
             }
             wg_sync();
+            if (tid < static_cast<int>(kQuadBuckets)) {
+                const uint32_t c = cntp[tid];
+                bp.preg_n[static_cast<uint64_t>(unit) * kQuadBuckets + static_cast<uint32_t>(tid)] = c < bp.preg_cap ? c : bp.preg_cap;
+            }
         }
         if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
         if (npend > 1u) atomicAdd(&hist_s[pend1], 1u);
@@ -2582,37 +2576,29 @@ __global__ __launch_bounds__(1024) void vk_quad_list_kernel(BucketParams bp) {
     }
 }
 
-// Pass B of the quad route: one 256-thread workgroup per (sample, bucket) replays the bucket's runs into two u32
-// tables of 4^(K-3) counters in LDS -- an entry's low 2K - 6 bits name its windows 0 and 1 (head, first tail base),
-// its bits [4, 2K - 2) its windows 2 and 3 (head without its first two bases, all three tail bases) -- and stores
-// them to bucket_hist[sample][bucket][2][4^(K-3)].  u32 counters: nothing can wrap, no second replay.
-// The first `nmisc_wgs` workgroups of the launch instead count the quads that pass A listed window by window (four
-// wavefront lists per workgroup): their global atomics run beside the replay.
+// Pass B of the quad route: one 512-thread workgroup per (sample, bucket) replays the bucket's runs into two u32
+// tables of 4^(K-3) counters in LDS -- an entry's low 2K - 6 bits name its windows 0 and 1 (head, first tail base: T0),
+// its bits [4, 2K - 2) its windows 2 and 3 (head without its first two bases, all three tail bases: T1).  The
+// bucket's listed quads follow: a whole pair of one goes into the same tables, a lone window t into R[t], the four
+// arrays of 4^(K-4) counters per window type that the job stores in the end --
+//     R[0][j] += sum over a of T0[j | a << HB]      R[1][j] += sum over a of T0[j << 2 | a]
+//     R[2][j] += sum over a of T1[j | a << HB]      R[3][j] += sum over a of T1[j << 2 | a]          (HB = 2K - 8)
+// (j = the window's K - 4 bases outside the bucket, first base lowest) -- to bucket_hist[sample][bucket][t][j'],
+// j' = j with its bases in reverse order (the merge reads them by k-mer code, last base lowest).
+// u32 counters: nothing can wrap, no second replay.
 template <int K>
-__global__ __launch_bounds__(256) void vk_quad_count_kernel(BucketParams bp, uint32_t* __restrict__ hist_out, uint32_t nmisc_wgs, uint32_t nlists,
-                                                            uint32_t lists_per_sample) {
-    constexpr uint32_t NCODE = 1u << (2 * K);
+__global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     constexpr uint32_t TB = 1u << (2 * K - 6);            // counters per table
+    constexpr uint32_t HB = 2 * K - 8;
+    constexpr uint32_t RB = 1u << HB;                     // counters per window array
     constexpr uint32_t M = (TB - 1u) << 2;                // byte offset mask
-    __shared__ uint32_t tab[2 * TB];
+    __shared__ __attribute__((aligned(16))) uint32_t tab[2 * TB];
+    __shared__ uint32_t rr[4 * RB];
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x < nmisc_wgs) {
-        const uint32_t li = blockIdx.x * 4u + (tid >> 6);   // the list = a wavefront of pass A's launch
-        if (li >= nlists) return;
-        // (pass A's grid: unit = sample * parts + part; lists per sample = parts * kWaves)
-        const uint32_t n = bp.misc_n[li];
-        const uint32_t* list = bp.misc + static_cast<uint64_t>(li) * bp.misc_cap;
-        const uint32_t s = li / lists_per_sample;
-        uint32_t* hist_s = hist_out + static_cast<uint64_t>(s) * NCODE;
-        for (uint32_t i = tid & 63u; i < n; i += 64u) {
-            const uint32_t e = list[i];
-            count_quad_direct<K>(hist_s, e & 0xFFFFFFu, e >> 24);
-        }
-        return;
-    }
-    const uint32_t job = blockIdx.x - nmisc_wgs;
+    const uint32_t job = blockIdx.x;
     const uint32_t s = job / kQuadBuckets, q = job % kQuadBuckets;
-    for (uint32_t i = tid; i < 2 * TB; i += 256) tab[i] = 0u;
+    for (uint32_t i = tid; i < 2 * TB; i += 512) tab[i] = 0u;
+    for (uint32_t i = tid; i < 4 * RB; i += 512) rr[i] = 0u;
     __syncthreads();
     const uint32_t* first = bp.qfirst + static_cast<uint64_t>(s) * (kQuadBuckets + 1);
     const uint32_t beg = first[q], end = first[q + 1];
@@ -2632,71 +2618,93 @@ __global__ __launch_bounds__(256) void vk_quad_count_kernel(BucketParams bp, uin
         tally2(v.z);
         tally2(v.w);
     };
-    // every thread reads granule g of a run (a run = 256 granules of 16 bytes: the whole workgroup per run), four
-    // runs in flight
+    // a run = 256 granules of 16 bytes: half of the workgroup per run (g = the thread's granule), two runs at a time,
+    // eight loads in flight per thread
+    const uint32_t g = tid & 255u, half = tid >> 8;
     auto fetch = [&](uint32_t i, uint4& v) __attribute__((always_inline)) -> bool {
         const uint32_t item = i < end ? list[i] : 0u;
-        const bool have = i < end && (tid >> 2) < (item >> 24);
-        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + tid);
+        const bool have = i < end && (g >> 2) < (item >> 24);
+        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
         return have;
     };
-    uint4 a0, a1, a2, a3, b0, b1, b2, b3;
-    bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
-    uint32_t i = beg;
-    ha0 = fetch(i, a0); ha1 = fetch(i + 1, a1); ha2 = fetch(i + 2, a2); ha3 = fetch(i + 3, a3);
-    while (i < end) {
-        hb0 = fetch(i + 4, b0); hb1 = fetch(i + 5, b1); hb2 = fetch(i + 6, b2); hb3 = fetch(i + 7, b3);
-        if (ha0) tally4(a0);
-        if (ha1) tally4(a1);
-        if (ha2) tally4(a2);
-        if (ha3) tally4(a3);
-        i += 4;
-        if (i >= end) break;
-        ha0 = fetch(i + 4, a0); ha1 = fetch(i + 5, a1); ha2 = fetch(i + 6, a2); ha3 = fetch(i + 7, a3);
-        if (hb0) tally4(b0);
-        if (hb1) tally4(b1);
-        if (hb2) tally4(b2);
-        if (hb3) tally4(b3);
-        i += 4;
+    {
+        uint4 a0, a1, a2, a3, b0, b1, b2, b3;
+        bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
+        uint32_t i = beg + half;
+        ha0 = fetch(i, a0); ha1 = fetch(i + 2, a1); ha2 = fetch(i + 4, a2); ha3 = fetch(i + 6, a3);
+        while (i < end) {
+            hb0 = fetch(i + 8, b0); hb1 = fetch(i + 10, b1); hb2 = fetch(i + 12, b2); hb3 = fetch(i + 14, b3);
+            if (ha0) tally4(a0);
+            if (ha1) tally4(a1);
+            if (ha2) tally4(a2);
+            if (ha3) tally4(a3);
+            i += 8;
+            if (i >= end) break;
+            ha0 = fetch(i + 8, a0); ha1 = fetch(i + 10, a1); ha2 = fetch(i + 12, a2); ha3 = fetch(i + 14, a3);
+            if (hb0) tally4(b0);
+            if (hb1) tally4(b1);
+            if (hb2) tally4(b2);
+            if (hb3) tally4(b3);
+            i += 8;
+        }
+    }
+    // the bucket's listed quads, a region per workgroup of pass A: x = K + 3 bases | OK bits << 24 (bit 24 + 2t: window t counts)
+    for (uint32_t p = 0; p < bp.parts; ++p) {
+        const uint64_t reg = (static_cast<uint64_t>(s) * bp.parts + p) * kQuadBuckets + q;
+        const uint32_t pe = bp.preg_n[reg];
+        const uint32_t* ps = bp.preg + reg * bp.preg_cap;
+        for (uint32_t i = tid; i < pe; i += 512) {
+            const uint32_t x = ps[i];
+            const uint32_t e = (x & (RB - 1u)) | (((x >> (2 * K)) & 63u) << HB);   // the quad's entry
+            const uint32_t i1 = e & (TB - 1u), i2 = (e >> 4) & (TB - 1u);
+            const uint32_t w0 = (x >> 24) & 1u, w1 = (x >> 26) & 1u, w2 = (x >> 28) & 1u, w3 = (x >> 30) & 1u;
+            if (w0 & w1) atomicAdd(&tab[i1], 1u);
+            else {
+                if (w0) atomicAdd(&rr[i1 & (RB - 1u)], 1u);
+                if (w1) atomicAdd(&rr[RB + (i1 >> 2)], 1u);
+            }
+            if (w2 & w3) atomicAdd(&tab[TB + i2], 1u);
+            else {
+                if (w2) atomicAdd(&rr[2 * RB + (i2 & (RB - 1u))], 1u);
+                if (w3) atomicAdd(&rr[3 * RB + (i2 >> 2)], 1u);
+            }
+        }
     }
     __syncthreads();
-    uint32_t* out = bp.bucket_hist + (static_cast<uint64_t>(s) * kQuadBuckets + q) * (2 * TB);
-    for (uint32_t j = tid; j < 2 * TB; j += 256) out[j] = tab[j];
+    uint32_t* out = bp.bucket_hist + (static_cast<uint64_t>(s) * kQuadBuckets + q) * (4 * RB);
+    for (uint32_t j = tid; j < RB; j += 512) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(tab + 4 * j), v1 = *reinterpret_cast<const uint4*>(tab + TB + 4 * j);
+        const uint32_t r0 = rr[j] + tab[j] + tab[j + RB] + tab[j + 2 * RB] + tab[j + 3 * RB];
+        const uint32_t r1 = rr[RB + j] + v0.x + v0.y + v0.z + v0.w;
+        const uint32_t r2 = rr[2 * RB + j] + tab[TB + j] + tab[TB + j + RB] + tab[TB + j + 2 * RB] + tab[TB + j + 3 * RB];
+        const uint32_t r3 = rr[3 * RB + j] + v1.x + v1.y + v1.z + v1.w;
+        const uint32_t jr = pair_reverse(j, K - 4);
+        out[jr] = r0;
+        out[RB + jr] = r1;
+        out[2 * RB + jr] = r2;
+        out[3 * RB + jr] = r3;
+    }
 }
 
-// Pass C of the quad route: one thread per k-mer code adds the sixteen counters that can name it -- as window t = 0 .. 3
-// of a quad: four counters each (the base of the pair that the window does not hold is any of four) -- to the histogram,
-// which already holds pass A's direct counts and the listed quads'.  raw = the code with its first base lowest.
+// Pass C of the quad route: one thread per k-mer code adds the four counters that can name it -- the code as window
+// t = 0 .. 3 of a quad: bucket = its bases K-4-t .. K-1-t, index = its other bases -- to the histogram, which already
+// holds pass A's direct counts.  (Indices with the LAST base lowest, as pass B stored them: the 4^t codes that differ
+// in their last t bases read neighbouring words.)
 template <int K>
 __global__ __launch_bounds__(256) void vk_quad_merge_kernel(BucketParams bp, uint32_t* __restrict__ hist_out) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr uint32_t TB = 1u << (2 * K - 6);
-    constexpr uint32_t HB = 2 * K - 8;                    // bits of an entry's head
+    constexpr uint32_t RB = 1u << (2 * K - 8);
     const uint32_t s = blockIdx.x / (NCODE / 256), code = (blockIdx.x % (NCODE / 256)) * 256 + threadIdx.x;
-    const uint32_t raw = pair_reverse(code, K);
-    const uint32_t* bh = bp.bucket_hist + static_cast<uint64_t>(s) * kQuadBuckets * (2 * TB);
+    const uint32_t* bh = bp.bucket_hist + static_cast<uint64_t>(s) * kQuadBuckets * (4 * RB);
     uint32_t add = 0;
-    {   // t = 0: bases b0 .. b(K-1): head = the first K - 4, bucket = the last four; the first tail base is any
-        const uint32_t q = raw >> HB, head = raw & ((1u << HB) - 1u);
-        const uint32_t* t = bh + static_cast<uint64_t>(q) * (2 * TB);
 #pragma unroll
-        for (uint32_t a = 0; a < 4; ++a) add += t[head | (a << HB)];
-    }
-    {   // t = 1: bases b1 .. b(K): b0 is any (the index's lowest two bits: one 16-byte load)
-        const uint32_t q = (raw >> (HB - 2)) & 0xFFu, head1 = raw & ((1u << (HB - 2)) - 1u), tail0 = raw >> (2 * K - 2);
-        const uint4 v = *reinterpret_cast<const uint4*>(bh + static_cast<uint64_t>(q) * (2 * TB) + ((head1 << 2) | (tail0 << HB)));
-        add += v.x + v.y + v.z + v.w;
-    }
-    {   // t = 2: bases b2 .. b(K+1): second table, index = (b2 .. b(K-5)) | tail << (2K - 12); the third tail base is any
-        const uint32_t q = (raw >> (HB - 4)) & 0xFFu, head2 = raw & ((1u << (HB - 4)) - 1u), tail01 = raw >> (2 * K - 4);
-        const uint32_t* t = bh + static_cast<uint64_t>(q) * (2 * TB) + TB;
-#pragma unroll
-        for (uint32_t a = 0; a < 4; ++a) add += t[head2 | (tail01 << (HB - 4)) | (a << HB)];
-    }
-    {   // t = 3: bases b3 .. b(K+2): b2 is any (lowest two bits of the index)
-        const uint32_t q = (raw >> (HB - 6)) & 0xFFu, head3 = raw & ((1u << (HB - 6)) - 1u), tail = raw >> (2 * K - 6);
-        const uint4 v = *reinterpret_cast<const uint4*>(bh + static_cast<uint64_t>(q) * (2 * TB) + TB + ((head3 << 2) | (tail << (HB - 4))));
-        add += v.x + v.y + v.z + v.w;
+    for (uint32_t t = 0; t < 4; ++t) {
+        // code = [first K-4-t bases | four bucket bases | last t bases], first base most significant
+        const uint32_t lastb = code & ((1u << (2 * t)) - 1u);
+        const uint32_t qc = (code >> (2 * t)) & 0xFFu;                 // the bucket's bases, first one most significant
+        const uint32_t firstb = code >> (2 * t + 8);
+        const uint32_t q = pair_reverse(qc, 4);                          // pass A's bucket number: first base lowest
+        add += bh[(static_cast<uint64_t>(q) * 4 + t) * RB + ((firstb << (2 * t)) | lastb)];
     }
     uint32_t* out = hist_out + static_cast<uint64_t>(s) * NCODE;
     out[code] += add;

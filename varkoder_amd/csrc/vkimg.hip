@@ -112,6 +112,7 @@ struct vk_ctx {
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
+    uint32_t spill_misc_cap = 0;   // VKIMG_SPILL_MISC_CAP=n: entries per (workgroup, bucket) region of the quad route's listed quads (tests)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
     bool spill_packed = false;     // VKIMG_SPILL_PACKED=1: k = 8, 9 pass A in two kernels, vk_pack_kernel + the partition of the packed stream (measured slower than the one kernel that classifies every byte: 21.1 against 16.3 ms per 100 samples; tests, A/B timing)
     bool spill_pairs = true;       // VKIMG_SPILL_QUADS=1 clears it: k = 8, 9 through the quad route (u16 per four windows, workgroup-shared queues) instead of the pair route of rounds 1-4
@@ -236,26 +237,28 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     return VK_OK;
 }
 
-// k = 8, 9, the quad route (vk_count.h: vk_bucket_kernel<K, 3>, vk_quad_list / _count / _merge_kernel), in sub-batches
-// that fit the spill budget.
+// k = 8, 9, the quad route (vk_count.h: vk_bucket_kernel<K, 3>, vk_quad_list / _count / _merge_kernel),
+// in sub-batches that fit the spill budget.
 template <int K>
 int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, const uint64_t* d_lens,
                       uint32_t nsamples, uint32_t parts, uint64_t maxlen, uint32_t* d_hist) {
     constexpr uint32_t NCODE = 1u << (2 * K);
-    constexpr size_t kTableWords = 2u << (2 * K - 6);   // the two tables of one bucket
+    constexpr size_t kOutWords = 4u << (2 * K - 8);   // what a pass B job stores: four window arrays of 4^(K-4) counters
     // Arena of one sample, in 4 KiB runs: a quad entry is 2 bytes and a FASTQ holds at most len / 8 quads (sequence
     // lines are less than half of the text), so len / 4 bytes however they spread over the 256 buckets; plus the
     // blocks a drain may leave unused at the end of a run, one open run per (workgroup, queue), one reserve per wave.
     uint64_t runs = (maxlen / 4 + maxlen / 32) / kRunBytes + 16 + static_cast<uint64_t>(parts) * (kQuadBuckets + kWaves * kPoolRuns);
     if (ctx->spill_runs_cap) runs = ctx->spill_runs_cap;  // VKIMG_SPILL_RUNS_CAP: tests force the arena-full fallback
     if (runs >= (1u << 24)) return VK_EINVAL;
-    // the waves' lists of quads counted window by window: ~19 per 4 KiB piece of 150-base reads; room for one per 32 bytes
-    const uint64_t wave_bytes = maxlen / (static_cast<uint64_t>(parts) * kWaves) + 64;
-    uint64_t mcap = wave_bytes / 32 + 64;
-    if (mcap > (1u << 24)) mcap = 1u << 24;
-    const size_t lists = static_cast<size_t>(parts) * kWaves;   // per sample
+    // the regions of quads of which only some windows count, one per (workgroup of pass A, bucket): ~1 per 215 bytes of
+    // 150-base reads over 256 buckets; room for four times that (uniform bases), at least 64
+    const uint64_t wg_bytes = maxlen / parts + 64 * kWaves;
+    uint64_t pcap = wg_bytes / 16384 + 64;
+    if (ctx->spill_misc_cap) pcap = ctx->spill_misc_cap;   // VKIMG_SPILL_MISC_CAP: tests force the region-full fallback
+    if (pcap > (1u << 22)) pcap = 1u << 22;                // (a region's byte offset stays below 2^32)
+    const size_t preg_words = static_cast<size_t>(parts) * kQuadBuckets * (pcap + 1);   // per sample: regions, populations
     const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (kQuadBuckets + 2) * sizeof(uint32_t) +
-                              kQuadBuckets * kTableWords * sizeof(uint32_t) + lists * (mcap + 1) * sizeof(uint32_t) + 64;
+                              kQuadBuckets * kOutWords * sizeof(uint32_t) + preg_words * sizeof(uint32_t) + 64;
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
     size_t budget = ctx->spill_budget;
@@ -264,13 +267,13 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     uint32_t batch = static_cast<uint32_t>(budget / per_sample);
     if (batch == 0) batch = 1;
     if (batch > nsamples) batch = nsamples;
-    // workspace: cursors[batch] | hdrs[batch][runs] (zeroed per sub-batch) | qfirst[batch][257] | qlist[batch][runs] |
-    //            misc_n[batch * lists] | misc[batch * lists][mcap] | bucket tables[batch][256][2][4^(K-3)] | arena[batch][runs][4 KiB]
+    // workspace: [zeroed per sub-batch: cursors[batch] | hdrs[batch][runs]] | qfirst[batch][257] | qlist[batch][runs] |
+    //            preg_n[batch * parts][256] | preg[batch * parts][256][pcap] | window arrays[batch][256][4][4^(K-4)] | arena[batch][runs][4 KiB]
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t head_bytes = up(static_cast<size_t>(batch) * (1 + runs) * sizeof(uint32_t));
     const size_t list_bytes = up(static_cast<size_t>(batch) * (kQuadBuckets + 1 + runs) * sizeof(uint32_t));
-    const size_t misc_bytes = up(static_cast<size_t>(batch) * lists * (mcap + 1) * sizeof(uint32_t));
-    const size_t bh_bytes = static_cast<size_t>(batch) * kQuadBuckets * kTableWords * sizeof(uint32_t);
+    const size_t misc_bytes = up(static_cast<size_t>(batch) * preg_words * sizeof(uint32_t));
+    const size_t bh_bytes = static_cast<size_t>(batch) * kQuadBuckets * kOutWords * sizeof(uint32_t);
     const size_t arena_bytes = static_cast<size_t>(batch) * runs * kRunBytes;
     int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_spill), &ctx->spill_cap, head_bytes + list_bytes + misc_bytes + bh_bytes + arena_bytes);
     if (rc) return rc;
@@ -280,9 +283,10 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     bp.hdrs = ctx->d_spill + batch;
     bp.qfirst = reinterpret_cast<uint32_t*>(base + head_bytes);
     bp.qlist = bp.qfirst + static_cast<size_t>(batch) * (kQuadBuckets + 1);
-    bp.misc_n = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes);
-    bp.misc = bp.misc_n + static_cast<size_t>(batch) * lists;
-    bp.misc_cap = static_cast<uint32_t>(mcap);
+    bp.preg_n = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes);
+    bp.preg = bp.preg_n + static_cast<size_t>(batch) * parts * kQuadBuckets;
+    bp.preg_cap = static_cast<uint32_t>(pcap);
+    bp.parts = parts;
     bp.bucket_hist = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes + misc_bytes);
     bp.arena = base + head_bytes + list_bytes + misc_bytes + bh_bytes;
     bp.runs_cap = static_cast<uint32_t>(runs);
@@ -300,14 +304,7 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(vk_quad_list_kernel, dim3(n), dim3(1024), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());
-        const uint32_t nlists = n * static_cast<uint32_t>(lists);
-#ifdef VK_DIAG_QUAD_NO_MISC   // timing only
-        const uint32_t nmisc_wgs = 0;
-#else
-        const uint32_t nmisc_wgs = (nlists + 3) / 4;
-#endif
-        hipLaunchKernelGGL((vk_quad_count_kernel<K>), dim3(nmisc_wgs + n * kQuadBuckets), dim3(256), 0, ctx->stream, bp, hist0,
-                           nmisc_wgs, nlists, static_cast<uint32_t>(lists));
+        hipLaunchKernelGGL((vk_quad_count_kernel<K>), dim3(n * kQuadBuckets), dim3(512), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_quad_merge_kernel<K>), dim3(n * (NCODE / 256)), dim3(256), 0, ctx->stream, bp, hist0);
         VK_HIP(ctx, hipGetLastError());
@@ -499,6 +496,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (r && r[0]) ctx->spill_runs_cap = static_cast<uint32_t>(strtoul(r, nullptr, 10));
         const char* tf = getenv("VKIMG_SPILL_PACKED");
         ctx->spill_packed = tf && tf[0] == '1';
+        const char* mc = getenv("VKIMG_SPILL_MISC_CAP");
+        if (mc && mc[0]) ctx->spill_misc_cap = static_cast<uint32_t>(strtoul(mc, nullptr, 10));
         const char* sq = getenv("VKIMG_SPILL_QUADS");
         ctx->spill_pairs = !(sq && sq[0] == '1');
         const char* fw = getenv("VKIMG_SPILL_FORCE_WIDE");

@@ -192,8 +192,30 @@ def test_full_size_fastp_shaped_sample_matches_oracle(engines, k, mapping):
         assert 0 < general <= pieces
 
 
+@pytest.fixture
+def route_engine(monkeypatch):
+    """An engine of its own for a k = 8, 9 test under extra environment: route "pairs" = VKIMG_SPILL_PAIRS=1 (the pair
+    route of rounds 1-4, which subsampled and packed launches still use), "quads" = the shipped quad route."""
+    from varkoder_amd.engine import ImageEngine
+    made = []
+
+    def make(k, route, **env):
+        if route == "pairs":
+            monkeypatch.setenv("VKIMG_SPILL_PAIRS", "1")
+        else:
+            monkeypatch.delenv("VKIMG_SPILL_PAIRS", raising=False)
+        for name, value in env.items():
+            monkeypatch.setenv(name, str(value))
+        made.append(ImageEngine(k=k, mapping="cgr", device=0))
+        return made[-1]
+    yield make
+    for e in made:
+        e.close()
+
+
+@pytest.mark.parametrize("route", ("quads", "pairs"))
 @pytest.mark.parametrize("k", (8, 9))
-def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
+def test_spill_path_skewed_input_takes_the_exact_fallbacks(route_engine, k, route):
     """k = 8, 9 bucket windows through LDS queues into per-part streams.  A low-complexity sample
     sends (almost) every window to ONE part: its queue and its bucket overflow, and the overflow
     must still be counted exactly (global-atomic fallbacks)."""
@@ -210,7 +232,7 @@ def test_spill_path_skewed_input_takes_the_exact_fallbacks(engines, k):
             seq = "".join(rng.choice(list("ACGT"), size=150))
         reads.append(rec(f"r{i}", seq))
     fq = b"".join(reads)
-    eng = engines(k)
+    eng = route_engine(k, route)
     want, nwin, st = oracle.count_fastq(fq, k)
     assert st == 0
     dev, offs, lens = eng.upload([fq, fq[: len(fq) // 2 - (len(fq) // 2) % 1 ]])
@@ -263,30 +285,50 @@ def test_low_complexity_runs_switch_the_window_loop_and_stay_exact(engines, k):
         assert np.array_equal(got[1], want2), parts
 
 
+@pytest.mark.parametrize("route", ("quads", "pairs"))
 @pytest.mark.parametrize("k", (8, 9))
-def test_spill_path_with_a_full_arena_counts_directly(k, monkeypatch):
+def test_spill_path_with_a_full_arena_counts_directly(route_engine, k, route):
     """The bucket streams of k = 8, 9 live in a per-sample arena of 4 KiB runs.  With the arena cut
     to a handful of runs (VKIMG_SPILL_RUNS_CAP) most blocks find no room and must be counted with
     global atomics instead: same histogram."""
-    from varkoder_amd.engine import ImageEngine
-    monkeypatch.setenv("VKIMG_SPILL_RUNS_CAP", "24")
-    eng = ImageEngine(k=k, mapping="cgr", device=0)
-    try:
-        samples = [synth.sample_fastq(40 + i, 6000, 150, dist=i & 1) for i in range(3)]
+    eng = route_engine(k, route, VKIMG_SPILL_RUNS_CAP=24)
+    samples = [synth.sample_fastq(40 + i, 6000, 150, dist=i & 1) for i in range(3)]
+    dev, offs, lens = eng.upload(samples)
+    for parts in (1, 3):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any()
+        got = hist.cpu().numpy().view(np.uint32)
+        for i, fq in enumerate(samples):
+            assert np.array_equal(got[i], oracle.count_fastq(fq, k)[0]), (parts, i)
+
+
+@pytest.mark.parametrize("k", (8, 9))
+def test_quad_route_with_full_regions_counts_directly(route_engine, k):
+    """Quads of which only some windows count (a read's first and last, the neighbours of an N) travel through a region
+    per (workgroup, bucket) of pass A; with the regions cut to four entries (VKIMG_SPILL_MISC_CAP = 2: a power of two) most of them find no
+    room and are counted window by window with global atomics: same histogram -- reads of every shape, reads riddled
+    with N, the edge cases."""
+    from fastq_cases import rec
+    rng = np.random.default_rng(31 + k)
+    holes = b"".join(rec(f"n{i}", "".join(rng.choice(list("ACGTN"), p=[0.24, 0.24, 0.24, 0.24, 0.04], size=int(rng.integers(20, 300)))))
+                     for i in range(3000))
+    samples = [synth.sample_fastq(90 + i, 6000, 150, dist=i % 3) for i in range(3)] + [holes] + list(edge_cases().values())
+    want = [oracle.count_fastq(s, k)[0] for s in samples]
+    for env in ({"VKIMG_SPILL_MISC_CAP": 2}, {}):
+        eng = route_engine(k, "quads", **env)
         dev, offs, lens = eng.upload(samples)
-        for parts in (1, 3):
+        for parts in (0, 1, 3):
             hist, status = eng.count(dev, offs, lens, parts=parts)
-            assert not status.cpu().numpy().any()
+            assert not status.cpu().numpy().any(), parts
             got = hist.cpu().numpy().view(np.uint32)
-            for i, fq in enumerate(samples):
-                assert np.array_equal(got[i], oracle.count_fastq(fq, k)[0]), (parts, i)
-    finally:
-        eng.close()
+            for i in range(len(samples)):
+                assert np.array_equal(got[i], want[i]), (env, parts, i)
 
 
 @pytest.mark.parametrize("k", (8, 9))
 def test_spill_replay_pair_counters_wrap_and_the_wide_replay_takes_over(engines, k, monkeypatch):
-    """Pass B of k = 8, 9 counts PAIRS in u16 counters; 65536 equal pairs in one bucket stream wrap one, the job's
+    """(The pair route, VKIMG_SPILL_PAIRS=1; the quad route's u32 counters cannot wrap: it counts the same sample first.)
+    Pass B of k = 8, 9 counts PAIRS in u16 counters; 65536 equal pairs in one bucket stream wrap one, the job's
     counters then do not add up to its entries and the job is replayed into u32 window counters
     (vk_bucket_count_wide_kernel).  A repeat of period 10 (beyond what the low-complexity shortcuts of pass A take
     out: period <= 8) in 60,000 reads does that to the buckets its pairs fall into, the random reads beside it keep
@@ -313,6 +355,16 @@ def test_spill_replay_pair_counters_wrap_and_the_wide_replay_takes_over(engines,
         hist, status = eng.count(dev, offs, lens, parts=parts)
         assert not status.cpu().numpy().any()
         assert np.array_equal(hist.cpu().numpy().view(np.uint32)[0], want), parts
+    monkeypatch.setenv("VKIMG_SPILL_PAIRS", "1")
+    e1 = ImageEngine(k=k, mapping="cgr", device=0)
+    try:
+        d1, o1, l1 = e1.upload([fq])
+        for parts in (1, 5):
+            hist, status = e1.count(d1, o1, l1, parts=parts)
+            assert not status.cpu().numpy().any()
+            assert np.array_equal(hist.cpu().numpy().view(np.uint32)[0], want), parts
+    finally:
+        e1.close()
     monkeypatch.setenv("VKIMG_SPILL_FORCE_WIDE", "1")
     e2 = ImageEngine(k=k, mapping="cgr", device=0)
     try:
@@ -325,6 +377,22 @@ def test_spill_replay_pair_counters_wrap_and_the_wide_replay_takes_over(engines,
         assert np.array_equal(got[3], want)
     finally:
         e2.close()
+
+
+@pytest.mark.parametrize("k", (8, 9))
+def test_spill_pair_route_still_counts_like_the_oracle(route_engine, k):
+    """VKIMG_SPILL_PAIRS=1: the plain count through the pair kernels (subsampled launches use them whatever the
+    environment says): synthetic batches of all three read shapes, the edge cases, several workgroup splits."""
+    eng = route_engine(k, "pairs")
+    samples = [synth.sample_fastq(60 + i, 8000, 150, dist=i % 3) for i in range(6)] + list(edge_cases().values())
+    want = [oracle.count_fastq(s, k)[0] for s in samples]
+    dev, offs, lens = eng.upload(samples)
+    for parts in (0, 1, 3):
+        hist, status = eng.count(dev, offs, lens, parts=parts)
+        assert not status.cpu().numpy().any(), parts
+        got = hist.cpu().numpy().view(np.uint32)
+        for i in range(len(samples)):
+            assert np.array_equal(got[i], want[i]), (parts, i)
 
 
 @pytest.mark.parametrize("k", (8, 9))

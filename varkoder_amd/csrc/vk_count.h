@@ -1562,9 +1562,9 @@ struct BucketParams {
     // the quad route (MODE 3 of vk_bucket_kernel; bsize / order / wide are not used by it):
     uint32_t* qfirst;    // [nsamples][kQuadBuckets + 1] first entry of every bucket's runs in qlist (vk_quad_list_kernel)
     uint32_t* qlist;     // [nsamples][runs_cap] closed runs sorted by bucket: run | filled blocks << 24
-    uint32_t* preg;      // [grid][kQuadBuckets][preg_cap] quads of which only some windows count, by pass A workgroup and bucket: K + 3 bases | OK bits << 24
+    uint32_t* preg;      // [grid][kQuadBuckets][1 << preg_shift] quads of which only some windows count, by pass A workgroup and bucket: K + 3 bases | OK bits << 24
     uint32_t* preg_n;    // [grid][kQuadBuckets] entries in each region
-    uint32_t preg_cap;
+    uint32_t preg_shift; // log2 of a region's capacity
     uint32_t parts;      // workgroups of pass A per sample
 };
 
@@ -1581,8 +1581,8 @@ constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // u
 constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
 constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
-constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [2]: the quad route's rounds of a step, agreed by the workgroup
-constexpr uint32_t kLdsCntP = kLdsSync + 8;                       // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
+constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [4]: the quad route's rounds of a step [2] and `tight` [2], agreed by the workgroup
+constexpr uint32_t kLdsCntP = kLdsSync + 16;                      // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
 static_assert(kLdsCntP + 256 * 4 <= kLdsQueues, "LDS layout");
 constexpr uint32_t kQuadBuckets = 256;    // the quad route's bucket streams per sample = kWaves * kQueues queues per WORKGROUP
 static_assert(kQuadBuckets == kWaves * kQueues, "a wave drains sixteen of its workgroup's queues");
@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         qused_all[wave * kQueues + lane] = kNoRun;
     }
     if (lane < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsPool)[wave * 2 + lane] = 0u;   // an empty reserve
-    if (tid < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
+    if (tid < 4) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
     if (QUAD && tid < static_cast<int>(kQuadBuckets)) reinterpret_cast<uint32_t*>(ldsb + kLdsCntP)[tid] = 0u;
     __syncthreads();
 
@@ -1909,35 +1909,51 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             wg_sync();
         };
         // The first drain point of a step (= one piece of every wave that still has pieces): the waves also agree on the
-        // number of drain points of the step, the largest number of append rounds any of them has (at least one).
+        // number of drain points of the step.  While the queues stay calm that is ONE: a step appends ~27 entries to a
+        // queue of 128 that starts it with at most 31 -- every further drain point costs the workgroup two barriers with a
+        // chain of LDS round trips between them (4 points in 10 wave cycles measured).  A wave that finds a queue three
+        // quarters full (skewed bases) raises `tight` for good: from the next step on, a drain point before every round
+        // of appends, as many as the busiest wave has.  (slots[step & 1]: rounds, slots[2 + (step & 1)]: tight -- written
+        // before the step's first barrier, read between its barriers: the same in every wave.)
         uint32_t qstep = 0;
         auto step_sync = [&](uint32_t rounds) __attribute__((always_inline)) -> uint32_t {
             uint32_t* const slots = reinterpret_cast<uint32_t*>(ldsb + kLdsSync);
             if (lane == 0 && rounds > 1u) atomicMax(&slots[qstep & 1u], rounds);
             wg_sync();
-            maybe_drain(kBlockBytes);
-            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
+            wave_lds_fence();
+            uint32_t n = qcnt[q];
+            const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
+            const bool tight = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[2u + (qstep & 1u)])) != 0;
+            const bool tight_now = __any(n >= 3u * kBlockBytes);
+            if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
+            if (__any(n >= kBlockBytes)) drain_all(n, n / kBlockBytes);
             if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
+            if (lane == 0 && (tight || tight_now)) slots[2u + ((qstep + 1u) & 1u)] = 1u;   // (sticky: only ever set)
             wg_sync();
             ++qstep;
-            return m > 1u ? m : 1u;
+            return tight && word > 1u ? word : 1u;
         };
         // Quads of which only some windows count (~1.5 per read) go to HBM as they are found, into the workgroup's region
         // of their bucket (pass B's job of the bucket reads the regions of the sample's workgroups): the place comes from a
         // returning LDS atomic on the workgroup's counter of the bucket; a full region: exact, slow.  (The words of a
         // region are written a few at a time, pieces apart, and meet in L2: 256 open lines per workgroup.)
         uint32_t* const cntp = reinterpret_cast<uint32_t*>(ldsb + kLdsCntP);
-        uint32_t* const pregion = QUAD ? bp.preg + static_cast<uint64_t>(unit) * kQuadBuckets * bp.preg_cap : nullptr;
-        auto partial = [&](bool have, uint32_t entry) __attribute__((always_inline)) {   // entry: K + 3 bases | OK bits << 24
-            const uint32_t bq = (entry >> (2 * K - 8)) & 0xFFu;
+        uint32_t* const pregion = QUAD ? bp.preg + ((static_cast<uint64_t>(unit) * kQuadBuckets) << bp.preg_shift) : nullptr;
+        // (in two steps, so that the atomic's round trip to LDS passes under the append block; preg_cap = 1 << preg_shift)
+        auto partial_reserve = [&](bool have, uint32_t entry) __attribute__((always_inline)) -> uint32_t {   // entry: K + 3 bases | OK bits << 24
             uint32_t a = 0xFFFFFFFFu;
-            if (have) a = atomicAdd(&cntp[bq], 1u);
-            if (a < bp.preg_cap) {
-                const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(pregion, 0, static_cast<int>(kQuadBuckets * bp.preg_cap * 4u), 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b32(entry, prsrc, (bq * bp.preg_cap + a) * 4u, 0, 0);
+            if (have) a = atomicAdd(&cntp[(entry >> (2 * K - 8)) & 0xFFu], 1u);
+            return a;
+        };
+        auto partial_store = [&](bool have, uint32_t entry, uint32_t a) __attribute__((always_inline)) {
+            const uint32_t cap = 1u << bp.preg_shift;
+            if (a < cap) {
+                const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(pregion, 0, static_cast<int>((kQuadBuckets * 4u) << bp.preg_shift), 0x00020000);
+                const uint32_t bq = (entry >> (2 * K - 8)) & 0xFFu;
+                __builtin_amdgcn_raw_buffer_store_b32(entry, prsrc, ((bq << bp.preg_shift) | a) << 2, 0, 0);
             }
-            if (__any(have && a >= bp.preg_cap)) {
-                if (have && a >= bp.preg_cap) count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);
+            if (__any(have && a >= cap)) {
+                if (have && a >= cap) count_quad_direct<K>(hist_s, entry & 0xFFFFFFu, entry >> 24);
             }
         };
 #ifdef VK_DIAG_K9_BARRIER   // timing only: what two workgroup barriers per piece cost
@@ -2021,6 +2037,23 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             const uint32_t p2 = okg & (okg >> 2), o2 = okg | (okg >> 2);
             const uint32_t all = p2 & (p2 >> 4) & 0x01010101u;
             const uint32_t some = ((o2 | (o2 >> 4)) & 0x01010101u) ^ all;
+#ifdef VK_DIAG_QUAD_NO_PARTIAL   // timing only
+            uint32_t rem = 0u & some;
+#else
+            uint32_t rem = some;
+#endif
+            // the lane's first quad of which only some windows count, in straight-line code (most calls find one in some
+            // lane, few lanes have two): its place is asked for here, it is stored behind the append block
+            auto entry_at = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {   // b = 8j
+                const uint32_t o = (32u - 2u * (K - 1) + b) & 63u;   // bit offset of the quad's first base in [lo | hi]
+                const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
+                const uint32_t xq = static_cast<uint32_t>(v >> o) & ((1u << (2 * K + 6)) - 1u);
+                return xq | (((okg >> (b & 31u)) & 0x55u) << 24);
+            };
+            const bool have0 = rem != 0u;
+            const uint32_t entry0 = entry_at(vkl::ffbl(rem) & 24u);
+            const uint32_t place0 = partial_reserve(have0, entry0);
+            rem &= rem - 1u;
             uint32_t x[4], f[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -2035,25 +2068,12 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 for (int j = 0; j < 4; ++j)
                     if (full & (1u << j)) count_quad_direct<K>(hist_s, x[j], 0x55u);
             }
-#ifdef VK_DIAG_QUAD_NO_PARTIAL   // timing only
-            uint32_t rem = 0u & some;
-#else
-            uint32_t rem = some;
-#endif
-            // the lane's first such quad in straight-line code (most calls find one in some lane, few lanes have two)
-            auto entry_at = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {   // b = 8j
-                const uint32_t o = (32u - 2u * (K - 1) + b) & 63u;   // bit offset of the quad's first base in [lo | hi]
-                const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
-                const uint32_t xq = static_cast<uint32_t>(v >> o) & ((1u << (2 * K + 6)) - 1u);
-                return xq | (((okg >> (b & 31u)) & 0x55u) << 24);
-            };
-            if (__any(rem != 0u)) {
-                partial(rem != 0u, entry_at(vkl::ffbl(rem) & 24u));
+            partial_store(have0, entry0, place0);
+            while (__any(rem != 0u)) {   // reads cut up by N, read ends that meet in one group
+                const bool have = rem != 0u;
+                const uint32_t entry = entry_at(vkl::ffbl(rem) & 24u);
+                partial_store(have, entry, partial_reserve(have, entry));
                 rem &= rem - 1u;
-                while (__any(rem != 0u)) {   // reads cut up by N, read ends that meet in one group
-                    partial(rem != 0u, entry_at(vkl::ffbl(rem) & 24u));
-                    rem &= rem - 1u;
-                }
             }
         };
         auto win = [&](uint32_t ch, const uint32_t* C, const uint32_t* ok_) __attribute__((always_inline)) {
@@ -2122,7 +2142,11 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                     const uint32_t lo = wave_prev_lane(e.x, xctx);
                     xctx = lane_bcast(e.x, 63);
                     if constexpr (QUAD) {
+#ifdef VK_DIAG_K9_NO_APPEND
+                        asm volatile("" :: "v"(lo), "v"(e.x), "v"(e.y));
+#else
                         append_quads(lo, e.x, e.y);
+#endif
                         if (synced < m) {   // a drain point before every further round of the step
                             mid_sync();
                             ++synced;
@@ -2232,7 +2256,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             wg_sync();
             if (tid < static_cast<int>(kQuadBuckets)) {
                 const uint32_t c = cntp[tid];
-                bp.preg_n[static_cast<uint64_t>(unit) * kQuadBuckets + static_cast<uint32_t>(tid)] = c < bp.preg_cap ? c : bp.preg_cap;
+                bp.preg_n[static_cast<uint64_t>(unit) * kQuadBuckets + static_cast<uint32_t>(tid)] = c < (1u << bp.preg_shift) ? c : (1u << bp.preg_shift);
             }
         }
         if (npend > 0u) atomicAdd(&hist_s[pend0], 1u);
@@ -2652,7 +2676,7 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     for (uint32_t p = 0; p < bp.parts; ++p) {
         const uint64_t reg = (static_cast<uint64_t>(s) * bp.parts + p) * kQuadBuckets + q;
         const uint32_t pe = bp.preg_n[reg];
-        const uint32_t* ps = bp.preg + reg * bp.preg_cap;
+        const uint32_t* ps = bp.preg + (reg << bp.preg_shift);
         for (uint32_t i = tid; i < pe; i += 512) {
             const uint32_t x = ps[i];
             const uint32_t e = (x & (RB - 1u)) | (((x >> (2 * K)) & 63u) << HB);   // the quad's entry

@@ -112,10 +112,10 @@ struct vk_ctx {
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     uint64_t last_waves = 0, last_bytes = 0;   // of the last count call: wave slots in d_wavephase, FASTQ bytes
     bool image_sort_only = false;  // VKIMG_IMAGE_SORT_ONLY=1: always take the sort kernel (tests, A/B timing)
-    uint32_t spill_misc_cap = 0;   // VKIMG_SPILL_MISC_CAP=n: entries per (workgroup, bucket) region of the quad route's listed quads (tests)
+    uint32_t spill_misc_cap = 0;   // VKIMG_SPILL_MISC_CAP=n: log2 of the entries per (workgroup, bucket) region of the quad route's listed quads (tests)
     uint32_t spill_runs_cap = 0;   // VKIMG_SPILL_RUNS_CAP=n: runs per sample arena of the k = 8, 9 path (tests)
     bool spill_packed = false;     // VKIMG_SPILL_PACKED=1: k = 8, 9 pass A in two kernels, vk_pack_kernel + the partition of the packed stream (measured slower than the one kernel that classifies every byte: 21.1 against 16.3 ms per 100 samples; tests, A/B timing)
-    bool spill_pairs = true;       // VKIMG_SPILL_QUADS=1 clears it: k = 8, 9 through the quad route (u16 per four windows, workgroup-shared queues) instead of the pair route of rounds 1-4
+    bool spill_pairs = false;      // VKIMG_SPILL_PAIRS=1: a plain k = 8, 9 count through the pair route of rounds 1-4 (u16 per two windows, wave-private queues; what subsampled and packed launches still use) instead of the quad route (tests, A/B timing)
     bool spill_force_wide = false; // VKIMG_SPILL_FORCE_WIDE=1: every k = 8, 9 replay job through the u32 window counters (tests)
     bool k1_classic = false;       // VKIMG_K1_CLASSIC=1: k <= 7 through vk_count_kernel (every byte through the heavy stage) instead of vk_count_dense_kernel (tests, A/B timing)
 };
@@ -253,9 +253,10 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     // the regions of quads of which only some windows count, one per (workgroup of pass A, bucket): ~1 per 215 bytes of
     // 150-base reads over 256 buckets; room for four times that (uniform bases), at least 64
     const uint64_t wg_bytes = maxlen / parts + 64 * kWaves;
-    uint64_t pcap = wg_bytes / 16384 + 64;
-    if (ctx->spill_misc_cap) pcap = ctx->spill_misc_cap;   // VKIMG_SPILL_MISC_CAP: tests force the region-full fallback
-    if (pcap > (1u << 22)) pcap = 1u << 22;                // (a region's byte offset stays below 2^32)
+    uint32_t pshift = 6;                                   // (a power of two: the place is a shift and an or)
+    while (pshift < 22 && (1ull << pshift) < wg_bytes / 16384 + 64) ++pshift;   // (at most 2^22: a region's byte offset stays below 2^32)
+    if (ctx->spill_misc_cap) pshift = ctx->spill_misc_cap < 22 ? ctx->spill_misc_cap : 22;   // VKIMG_SPILL_MISC_CAP (log2): tests force the region-full fallback
+    const uint64_t pcap = 1ull << pshift;
     const size_t preg_words = static_cast<size_t>(parts) * kQuadBuckets * (pcap + 1);   // per sample: regions, populations
     const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (kQuadBuckets + 2) * sizeof(uint32_t) +
                               kQuadBuckets * kOutWords * sizeof(uint32_t) + preg_words * sizeof(uint32_t) + 64;
@@ -285,7 +286,7 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     bp.qlist = bp.qfirst + static_cast<size_t>(batch) * (kQuadBuckets + 1);
     bp.preg_n = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes);
     bp.preg = bp.preg_n + static_cast<size_t>(batch) * parts * kQuadBuckets;
-    bp.preg_cap = static_cast<uint32_t>(pcap);
+    bp.preg_shift = pshift;
     bp.parts = parts;
     bp.bucket_hist = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes + misc_bytes);
     bp.arena = base + head_bytes + list_bytes + misc_bytes + bh_bytes;
@@ -498,8 +499,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         ctx->spill_packed = tf && tf[0] == '1';
         const char* mc = getenv("VKIMG_SPILL_MISC_CAP");
         if (mc && mc[0]) ctx->spill_misc_cap = static_cast<uint32_t>(strtoul(mc, nullptr, 10));
-        const char* sq = getenv("VKIMG_SPILL_QUADS");
-        ctx->spill_pairs = !(sq && sq[0] == '1');
+        const char* sq = getenv("VKIMG_SPILL_PAIRS");
+        ctx->spill_pairs = sq && sq[0] == '1';
         const char* fw = getenv("VKIMG_SPILL_FORCE_WIDE");
         ctx->spill_force_wide = fw && fw[0] == '1';
         const char* kc = getenv("VKIMG_K1_CLASSIC");

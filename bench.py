@@ -384,7 +384,7 @@ def config4(args, device_index):
     """BASELINE.json configs[3] as a side leg of the N=1 line: k=9 cgr images (512x512), 1M 150 bp reads
     per sample, 100 samples, every sample distinct (pool = samples), for the uniform and the GC-skew +
     homopolymer base distribution.  4^9 u32 counters do not fit LDS: this is the spill path
-    (vk_bucket_kernel -> vk_bucket_order_kernel -> vk_bucket_count_kernel -> vk_bucket_merge_kernel).
+    (the quad route: vk_bucket_kernel<9, 3> -> vk_quad_list_kernel -> vk_quad_count_kernel -> vk_quad_merge_kernel).
     Times are HIP events on the launch stream around the count and the image call; `frac` is against the
     same HBM peak as the main line (algorithmic bytes = text read once + the 1 MiB histogram written once
     per sample); `traffic` and the per-kernel times come from profiles/k9_latest.json when that file was
@@ -435,7 +435,7 @@ def config4(args, device_index):
         leg = {"ms_per_step": wall * 1e3, "count_ms": count_ms, "image_ms": image_ms,
                "gbases_per_s": bases / wall / 1e9, "fastq_bytes": int(np.sum(lens)),
                "bad_status_samples": int((status != 0).sum().item()), "count_launch": eng.last_count_launch(),
-               "roofline": {"bound": "hbm", "kernel": "vk_bucket_kernel + vk_bucket_count_kernel + vk_bucket_merge_kernel",
+               "roofline": {"bound": "hbm", "kernel": "vk_bucket_kernel<9,3> + vk_quad_list_kernel + vk_quad_count_kernel + vk_quad_merge_kernel",
                             "achieved": alg / (count_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": alg / (count_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
                             "traffic": None, "kernel_ms_profiled": None,
@@ -720,7 +720,7 @@ def main():
                 traffic = None
         # the kernel the count call launches (rocprofv3's name for it): k <= 7 the sequence-only dense kernel
         # unless VKIMG_K1_CLASSIC=1 asks for the kernel that classifies every byte; k = 8, 9 the spill path
-        count_kernel = ("vk_bucket_kernel+vk_bucket_count_kernel+vk_bucket_merge_kernel" if args.k > 7 else
+        count_kernel = ("vk_bucket_kernel+vk_quad_list_kernel+vk_quad_count_kernel+vk_quad_merge_kernel" if args.k > 7 else
                         "vk_count_kernel" if os.environ.get("VKIMG_K1_CLASSIC") == "1" else "vk_count_dense_kernel")
         out = {
             "metric": "Gbases/s for `varKoder image` k=%d, %d bp reads" % (args.k, args.readlen),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summaries of the k=9 (BASELINE config 4) profiles: python profiles/summarize_k9.py <tag_dist0> <tag_dist1>
+"""Summaries of the k=9 (BASELINE config 4) profiles: python profiles/summarize_k9.py <tag_dist0> <tag_dist1> [<tag_dist2>]
 reads gpurun_out/prof_<tag>/ (profiles/run_k9_pmc.sh), writes profiles/<tag>/ (kernel_stats.csv,
 pmc_summary.json, traffic.json) and profiles/k9_latest.json, which bench.py's `config4` leg quotes when its
 configuration matches.  HBM bytes: FETCH_SIZE (KB) x 2 (gfx950: a wide streaming read is tallied at half,
@@ -36,10 +36,10 @@ for tag in sys.argv[1:]:
     json.dump(pmc, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1, sort_keys=True)
     kernel_ms = {}
     for r in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
-        m = re.search(r"vk_bucket\w*|vk_check_kernel|vk_image\w*", r["Name"])
+        m = re.search(r"vk_bucket\w*|vk_quad\w*|vk_check_kernel|vk_image\w*", r["Name"])
         if m:
             kernel_ms[m.group(0)] = float(r["AverageNs"]) / 1e6
-    spill = [k for k in pmc if k.startswith("vk_bucket")]
+    spill = [k for k in pmc if k.startswith(("vk_bucket", "vk_quad"))]
     fetch = sum(pmc[k].get("FETCH_SIZE", {}).get("mean_per_dispatch", 0.0) for k in spill) * 1024 * 2
     write = sum(pmc[k].get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) for k in spill) * 1024
     cfg = None

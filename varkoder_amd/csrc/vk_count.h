@@ -1559,7 +1559,7 @@ struct BucketParams {
     uint32_t* wide;      // [nsamples * 16] != 0: the job's u16 pair counters overflowed, bucket_hist holds u32 window counters instead
     uint32_t runs_cap;
     uint32_t force_wide; // tests: every job through the u32 replay
-    // the quad route (MODE 3 of vk_bucket_kernel; bsize / order / wide are not used by it):
+    // the quad route (MODE 3 of vk_bucket_kernel; bsize = runs per bucket, [nsamples][kQuadBuckets]; wide is not used by it):
     uint32_t* qfirst;    // [nsamples][kQuadBuckets + 1] first entry of every bucket's runs in qlist (vk_quad_list_kernel)
     uint32_t* qlist;     // [nsamples][runs_cap] closed runs sorted by bucket: run | filled blocks << 24
     uint32_t* preg;      // [grid][kQuadBuckets][1 << preg_shift] quads of which only some windows count, by pass A workgroup and bucket: K + 3 bases | OK bits << 24
@@ -2221,8 +2221,11 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
                 win(ch, C, ok);
             }
         } else {
+#ifndef VK_QUAD_PF
+#define VK_QUAD_PF 0
+#endif
             if (!QUAD || !wr.empty)
-                wave_stream<K, SUB, SUB ? 1 : 0>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
+                wave_stream<K, SUB, SUB ? 1 : (QUAD ? VK_QUAD_PF : 0)>(sbase, len, wr.w0, wr.w1, scratch_all + wave * 8, below, above, lane, win,
                                                         piece_start, ph_start, ph_end, sw);
         }
         if constexpr (SUB) flush_sites(sp, s, sw, lane);
@@ -2592,6 +2595,7 @@ __global__ __launch_bounds__(1024) void vk_quad_list_kernel(BucketParams bp) {
         first[4 * tid + 3] = before + c0 + c1 + c2;
         if (tid == 63) first[kQuadBuckets] = before + sum;
     }
+    if (tid < kQuadBuckets) bp.bsize[s * kQuadBuckets + tid] = cnt[tid];   // the job's size for vk_bucket_order_kernel: its runs
     __syncthreads();
     uint32_t* list = bp.qlist + static_cast<uint64_t>(s) * bp.runs_cap;
     for (uint32_t r = tid; r < nruns; r += 1024) {
@@ -2619,7 +2623,7 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     __shared__ __attribute__((aligned(16))) uint32_t tab[2 * TB];
     __shared__ uint32_t rr[4 * RB];
     const uint32_t tid = threadIdx.x;
-    const uint32_t job = blockIdx.x;
+    const uint32_t job = bp.order[blockIdx.x];  // large streams first (vk_bucket_order_kernel): skewed bases make some buckets several times the average
     const uint32_t s = job / kQuadBuckets, q = job % kQuadBuckets;
     for (uint32_t i = tid; i < 2 * TB; i += 512) tab[i] = 0u;
     for (uint32_t i = tid; i < 4 * RB; i += 512) rr[i] = 0u;

@@ -258,7 +258,7 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     if (ctx->spill_misc_cap) pshift = ctx->spill_misc_cap < 22 ? ctx->spill_misc_cap : 22;   // VKIMG_SPILL_MISC_CAP (log2): tests force the region-full fallback
     const uint64_t pcap = 1ull << pshift;
     const size_t preg_words = static_cast<size_t>(parts) * kQuadBuckets * (pcap + 1);   // per sample: regions, populations
-    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (kQuadBuckets + 2) * sizeof(uint32_t) +
+    const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (3 * kQuadBuckets + 2) * sizeof(uint32_t) +
                               kQuadBuckets * kOutWords * sizeof(uint32_t) + preg_words * sizeof(uint32_t) + 64;
     size_t free_b = 0, total_b = 0;
     VK_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -272,7 +272,7 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     //            preg_n[batch * parts][256] | preg[batch * parts][256][pcap] | window arrays[batch][256][4][4^(K-4)] | arena[batch][runs][4 KiB]
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t head_bytes = up(static_cast<size_t>(batch) * (1 + runs) * sizeof(uint32_t));
-    const size_t list_bytes = up(static_cast<size_t>(batch) * (kQuadBuckets + 1 + runs) * sizeof(uint32_t));
+    const size_t list_bytes = up(static_cast<size_t>(batch) * (3 * kQuadBuckets + 1 + runs) * sizeof(uint32_t));   // qfirst | qlist | job sizes | job order
     const size_t misc_bytes = up(static_cast<size_t>(batch) * preg_words * sizeof(uint32_t));
     const size_t bh_bytes = static_cast<size_t>(batch) * kQuadBuckets * kOutWords * sizeof(uint32_t);
     const size_t arena_bytes = static_cast<size_t>(batch) * runs * kRunBytes;
@@ -284,6 +284,8 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     bp.hdrs = ctx->d_spill + batch;
     bp.qfirst = reinterpret_cast<uint32_t*>(base + head_bytes);
     bp.qlist = bp.qfirst + static_cast<size_t>(batch) * (kQuadBuckets + 1);
+    bp.bsize = bp.qlist + static_cast<size_t>(batch) * runs;
+    bp.order = bp.bsize + static_cast<size_t>(batch) * kQuadBuckets;
     bp.preg_n = reinterpret_cast<uint32_t*>(base + head_bytes + list_bytes);
     bp.preg = bp.preg_n + static_cast<size_t>(batch) * parts * kQuadBuckets;
     bp.preg_shift = pshift;
@@ -304,6 +306,8 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
                            d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, PackParams{});
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(vk_quad_list_kernel, dim3(n), dim3(1024), 0, ctx->stream, bp);
+        VK_HIP(ctx, hipGetLastError());
+        hipLaunchKernelGGL(vk_bucket_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, bp, n * kQuadBuckets);
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_quad_count_kernel<K>), dim3(n * kQuadBuckets), dim3(512), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());

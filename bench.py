@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--config4-samples", type=int, default=100)
     ap.add_argument("--config4-steps", type=int, default=5)
     ap.add_argument("--no-ladder", action="store_true", help="skip the subsample-ladder leg (N=1 only)")
+    ap.add_argument("--no-query", action="store_true", help="skip the images -> preprocess -> forward leg (BASELINE configs[4], N=1 only)")
+    ap.add_argument("--query-samples", type=int, default=512)
+    ap.add_argument("--query-batch", type=int, default=256)
+    ap.add_argument("--query-steps", type=int, default=3)
     ap.add_argument("--ladder-samples", type=int, default=32)
     ap.add_argument("--no-realistic", action="store_true", help="skip the fastp-shaped read-length leg (N=1 only)")
     ap.add_argument("--realistic-pool", type=int, default=256)
@@ -538,6 +542,92 @@ def ladder(args, device_index):
                     "rest (vk_count_index_device, vk_walk_kernel); round 3 streamed the text once per step (38.2 ms for 32 x 12)" % args.k}
 
 
+def query_leg(args, device_index):
+    """BASELINE.json configs[4] on ONE GPU: FASTQ resident in HBM -> count -> image (stays on the device) ->
+    vk_preprocess_device (PIL's BOX squish to 224 x 224, /255, normalise: query.py) -> batched forward of a model with the
+    shape of the reference's default architecture (timm vit_large_patch32_224, core/config.py:51-52; random weights --
+    fastai / timm / the hub weights need a network) at the reference's `get_preds` precision (fp32, commands/query.py:283-324)
+    -> sigmoid >= threshold.  Times: HIP events on the current stream (the engine launches on it); the preprocess kernel's
+    rate is against its own bytes (u8 image read once, three float32 planes written).  `verified`: the float tensors of
+    four images must equal a PIL + NumPy restatement of the reference's item transform bit for bit, else the leg fails."""
+    import torch
+    from varkoder_amd import query as Q
+    from varkoder_amd.engine import ImageEngine
+    n, pool, k, mapping, bs = args.query_samples, min(64, args.query_samples), 7, "cgr", args.query_batch
+    eng = ImageEngine(k=k, mapping=mapping, device=device_index)
+    dev = torch.device("cuda", device_index)
+    buf, poffs, plens = eng.synth(9000, pool, args.reads, args.readlen, dist=args.dist)
+    idx = np.arange(n) % pool
+    offs, lens = poffs[idx].copy(), plens[idx].copy()
+    torch.manual_seed(0)
+    model = Q.vit().to(dev).eval()
+    nparam = sum(p.numel() for p in model.parameters())
+    out_size, thr = 224, 0.7
+
+    def one_pass(ev=None):
+        if ev:
+            ev[0].record()
+        img, hist, status = eng.fastq_to_images(buf, offs, lens)
+        if ev:
+            ev[1].record()
+        pre_ms = fwd_ms = 0.0
+        hits = 0
+        pev = []
+        with torch.no_grad():
+            for i in range(0, n, bs):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record()
+                x = Q.preprocess(eng, img[i:i + bs].contiguous(), out_size=out_size)
+                e[1].record()
+                probs = torch.sigmoid(model(x))
+                hits_t = (probs >= thr).sum()
+                e[2].record()
+                pev.append((e, hits_t))
+        if ev:
+            ev[2].record()
+        torch.cuda.synchronize()
+        for e, h in pev:
+            pre_ms += e[0].elapsed_time(e[1])
+            fwd_ms += e[1].elapsed_time(e[2])
+            hits += int(h.item())
+        return img, status, pre_ms, fwd_ms, hits
+
+    one_pass()                                             # warm-up: workspaces, GEMM algorithm selection
+    res = []
+    for _ in range(args.query_steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t0 = time.perf_counter()
+        img, status, pre_ms, fwd_ms, hits = one_pass(ev)
+        wall = time.perf_counter() - t0
+        res.append((wall, ev[0].elapsed_time(ev[1]), pre_ms, fwd_ms, hits))
+    wall, img_ms, pre_ms, fwd_ms, hits = sorted(res)[len(res) // 2]
+    # the four images the check looks at: the device transform against PIL's resize + float32 arithmetic
+    from PIL import Image
+    host = img[:4].cpu().numpy()
+    got = Q.preprocess(eng, img[:4].contiguous(), out_size=out_size).cpu().numpy()
+    verified = 0
+    for i in range(4):
+        r = np.array(Image.fromarray(host[i]).convert("RGB").resize((out_size, out_size), resample=Image.Resampling.BOX))
+        want = np.ascontiguousarray(((r.astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)).transpose(2, 0, 1))
+        if not np.array_equal(got[i], want):
+            raise VerifyError("query leg: preprocess tensor of image %d differs from the PIL pipeline" % i)
+        verified += 1
+    pre_bytes = n * (eng.side * eng.side + 3 * out_size * out_size * 4)
+    bad = int((status != 0).sum().item())
+    eng.close()
+    del buf, model
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE configs[4] on one GPU: %d samples x %d x %d bp reads (pool %d), k=%d %s -> %dx%d images on the device -> "
+                        "BOX squish to %dx%d + normalise -> ViT-L/32-224-shaped forward (%d M parameters, random weights, fp32, batch %d) -> "
+                        "sigmoid >= %.1f" % (n, args.reads, args.readlen, pool, k, mapping, eng.side, eng.side, out_size, out_size, nparam // 1000000, bs, thr),
+            "samples": n, "steps": args.query_steps, "ms_per_pass": wall * 1e3, "images_per_s": n / wall,
+            "gbases_per_s": n * args.reads * args.readlen / wall / 1e9,
+            "count_and_image_ms": img_ms, "preprocess_ms": pre_ms, "forward_ms": fwd_ms,
+            "forward_share": fwd_ms / (wall * 1e3), "preprocess_gb_per_s": pre_bytes / (pre_ms * 1e-3) / 1e9,
+            "preprocess_bytes": pre_bytes, "labels_over_threshold": hits, "bad_status_samples": bad,
+            "verified_preprocess_images": verified, "dtype": "u32 counts, u8 images, float32 transform and forward"}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -786,6 +876,15 @@ def main():
                 out["ladder"] = ladder(args, local_rank)
             except Exception as e:  # a side measurement: never lose the bench line over it
                 out["ladder"] = {"error": repr(e)}
+        if world == 1 and not args.no_query and args.k <= 7:
+            try:
+                out["query"] = query_leg(args, local_rank)
+            except VerifyError as e:
+                out["query"] = {"error": repr(e)}
+                out["verify_failed"] = str(e)
+                bad = max(bad, 1)
+            except Exception as e:  # a side measurement: never lose the bench line over it
+                out["query"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e:
             try:
                 out["end_to_end"] = end_to_end(eng, args)

@@ -264,7 +264,8 @@ def test_bench_script_runs_end_to_end(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
                           "--samples", "16", "--pool", "8", "--reads", "20000", "--cpu-seconds", "0.5", "--e2e-files", "6",
-                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2", "--realistic-pool", "8", "--realistic-steps", "2", "--ladder-samples", "3"],
+                          "--e2e-reads", "5000", "--config4-samples", "6", "--config4-steps", "2", "--realistic-pool", "8", "--realistic-steps", "2", "--ladder-samples", "3",
+                          "--query-samples", "12", "--query-batch", "8", "--query-steps", "2"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -294,6 +295,10 @@ def test_bench_script_runs_end_to_end(tmp_path):
     assert c4["dist2"]["fastq_bytes"] != c4["dist0"]["fastq_bytes"]
     # the line checks itself: the first batch entries' histograms and images against the oracle's
     assert d["verified_samples"] == 4 and d["cpu_baseline"]["verified_samples"] == 4 and "verify_failed" not in d
+    qy = d["query"]                                     # BASELINE configs[4] on one GPU: images -> input transform -> forward
+    assert qy["samples"] == 12 and qy["verified_preprocess_images"] == 4 and qy["bad_status_samples"] == 0
+    assert qy["images_per_s"] > 0 and qy["preprocess_ms"] > 0 and qy["forward_ms"] > 0 and 0 < qy["forward_share"] < 1
+    assert abs(qy["preprocess_gb_per_s"] - qy["preprocess_bytes"] / (qy["preprocess_ms"] * 1e-3) / 1e9) < 1e-6
     rl = d["realistic"]                                 # reads of the lengths fastp writes (synth.py dist 2)
     for leg in ("dense", "classic"):
         assert rl[leg]["bad_status_samples"] == 0 and rl[leg]["count_ms"] > 0

@@ -1581,8 +1581,8 @@ constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // u
 constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
 constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
-constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [4]: the quad route's rounds of a step [2] and `tight` [2], agreed by the workgroup
-constexpr uint32_t kLdsCntP = kLdsSync + 16;                      // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
+constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [6]: the quad route's rounds of a step [2], `tight` [2] and "some wave appends" [2], agreed by the workgroup
+constexpr uint32_t kLdsCntP = kLdsSync + 24;                      // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
 static_assert(kLdsCntP + 256 * 4 <= kLdsQueues, "LDS layout");
 constexpr uint32_t kQuadBuckets = 256;    // the quad route's bucket streams per sample = kWaves * kQueues queues per WORKGROUP
 static_assert(kQuadBuckets == kWaves * kQueues, "a wave drains sixteen of its workgroup's queues");
@@ -1629,13 +1629,31 @@ __device__ __forceinline__ uint32_t quad_bases(uint32_t q, uint32_t e) {   // bu
     constexpr uint32_t HB = 2 * K - 8;
     return (e & ((1u << HB) - 1u)) | (q << HB) | (((e >> HB) & 63u) << (2 * K));
 }
-// the windows of a quad named by the OK bits `okb` (bit 2t: window t), counted directly
+// the windows of a quad named by the OK bits `okb` (bit 2t: window t), counted directly (n times)
 template <int K>
-__device__ __forceinline__ void count_quad_direct(uint32_t* hist_s, uint32_t x, uint32_t okb) {
+__device__ __forceinline__ void count_quad_direct(uint32_t* hist_s, uint32_t x, uint32_t okb, uint32_t n = 1u) {
     constexpr uint32_t FMASK = (1u << (2 * K)) - 1u;
 #pragma unroll
     for (uint32_t t = 0; t < 4; ++t)
-        if ((okb >> (2u * t)) & 1u) atomicAdd(&hist_s[pair_reverse((x >> (2u * t)) & FMASK, K)], 1u);
+        if ((okb >> (2u * t)) & 1u) atomicAdd(&hist_s[pair_reverse((x >> (2u * t)) & FMASK, K)], n);
+}
+// The same for the lanes of a wavefront that hold a whole quad (`have`), equal quads counted ONCE with their number:
+// what a full queue sends here is low-complexity input, where 64 lanes hold a handful of different quads -- and 64
+// global atomics on one counter are carried out one after the other at the memory side.  Up to eight classes; what
+// is left after that counts alone.  All lanes call it.
+// (a function of its own: inlined at the append sites it cost the piece loop 18 vector instructions per piece in moves)
+template <int K>
+__device__ __attribute__((noinline)) void count_quads_aggregated(uint32_t* hist_s, bool have, uint32_t x) {
+    const uint32_t key = x & ((1u << (2 * K + 6)) - 1u);
+    unsigned long long left = __ballot(have);
+    for (int t = 0; t < 8 && left != 0ull; ++t) {
+        const int src = __builtin_ctzll(left);
+        const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), src));
+        const unsigned long long eq = __ballot(have && key == first) & left;
+        if (lane_now() == static_cast<uint32_t>(src)) count_quad_direct<K>(hist_s, first, 0x55u, static_cast<uint32_t>(__builtin_popcountll(eq)));
+        left &= ~eq;
+    }
+    if ((left >> lane_now()) & 1ull) count_quad_direct<K>(hist_s, key, 0x55u);
 }
 
 __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
@@ -1685,7 +1703,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         qused_all[wave * kQueues + lane] = kNoRun;
     }
     if (lane < 2) reinterpret_cast<uint32_t*>(ldsb + kLdsPool)[wave * 2 + lane] = 0u;   // an empty reserve
-    if (tid < 4) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
+    if (tid < 6) reinterpret_cast<uint32_t*>(ldsb + kLdsSync)[tid] = 0u;
     if (QUAD && tid < static_cast<int>(kQuadBuckets)) reinterpret_cast<uint32_t*>(ldsb + kLdsCntP)[tid] = 0u;
     __syncthreads();
 
@@ -1915,22 +1933,37 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         // quarters full (skewed bases) raises `tight` for good: from the next step on, a drain point before every round
         // of appends, as many as the busiest wave has.  (slots[step & 1]: rounds, slots[2 + (step & 1)]: tight -- written
         // before the step's first barrier, read between its barriers: the same in every wave.)
-        uint32_t qstep = 0;
+        // A step in which NO wave appends (stretches of homopolymer reads, which the shortcut in `win` counts) makes the
+        // next kIdleSteps steps go without a drain point: the queues hold less than a block each then and take a few
+        // steps' appends; more than that overflows into the exact direct count.  (An even number: the slots alternate.)
+        constexpr uint32_t kIdleSteps = 6;
+        uint32_t qstep = 0, idle_left = 0;
         auto step_sync = [&](uint32_t rounds) __attribute__((always_inline)) -> uint32_t {
+            if (idle_left != 0u) {   // (wave-uniform and the same in every wave: set from the slot word below)
+                --idle_left;
+                ++qstep;
+                return 1u;
+            }
             uint32_t* const slots = reinterpret_cast<uint32_t*>(ldsb + kLdsSync);
             if (lane == 0 && rounds > 1u) atomicMax(&slots[qstep & 1u], rounds);
+            if (lane == 0 && rounds > 0u) slots[4u + (qstep & 1u)] = 1u;   // (a plain store: every writer writes the same)
             wg_sync();
             wave_lds_fence();
             uint32_t n = qcnt[q];
             const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
             const bool tight = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[2u + (qstep & 1u)])) != 0;
+            const bool active = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[4u + (qstep & 1u)])) != 0;
             const bool tight_now = __any(n >= 3u * kBlockBytes);
             if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
             if (__any(n >= kBlockBytes)) drain_all(n, n / kBlockBytes);
-            if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
+            if (tid == 0) {   // (the next step's slots: last read before this step's first barrier)
+                slots[(qstep + 1u) & 1u] = 0u;
+                slots[4u + ((qstep + 1u) & 1u)] = 0u;
+            }
             if (lane == 0 && (tight || tight_now)) slots[2u + ((qstep + 1u) & 1u)] = 1u;   // (sticky: only ever set)
             wg_sync();
             ++qstep;
+            if (!active) idle_left = kIdleSteps;
             return tight && word > 1u ? word : 1u;
         };
         // Quads of which only some windows count (~1.5 per read) go to HBM as they are found, into the workgroup's region
@@ -2063,10 +2096,9 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
             const uint32_t full = append4(x, f);
             if (__any(full != 0u)) hot = true;
-            if (full) {  // rare: the queue was full, count the quad directly
+            if (__any(full != 0u)) {  // rare: a queue was full, count those quads directly
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (full & (1u << j)) count_quad_direct<K>(hist_s, x[j], 0x55u);
+                for (int j = 0; j < 4; ++j) count_quads_aggregated<K>(hist_s, (full & (1u << j)) != 0u, x[j]);
             }
             partial_store(have0, entry0, place0);
             while (__any(rem != 0u)) {   // reads cut up by N, read ends that meet in one group

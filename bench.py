@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--config4-samples", type=int, default=100)
     ap.add_argument("--config4-steps", type=int, default=5)
     ap.add_argument("--no-ladder", action="store_true", help="skip the subsample-ladder leg (N=1 only)")
+    ap.add_argument("--ladder-shard-samples", type=int, default=16, help="samples of the N > 1 leg with ladder-shaped (unequal) units; 0 = skip")
     ap.add_argument("--no-query", action="store_true", help="skip the images -> preprocess -> forward leg (BASELINE configs[4], N=1 only)")
     ap.add_argument("--query-samples", type=int, default=512)
     ap.add_argument("--query-batch", type=int, default=256)
@@ -382,6 +383,65 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res
+
+
+def ladder_shard(eng, args, rank, world, dist, red_dev):
+    """N > 1: units of UNEQUAL size -- the files `split_fastqs/` holds for `--ladder-shard-samples` samples, one per rung of
+    the reference's test ladder (-m 500K -M 20M: 500K, 1M, 2M, 5M, 10M, 20M bases, commands/image.py:682-708,
+    tests/02_constants.sh:32), sorted by name as the CLI lists them -- sharded over the ranks by size (shard.shard_by_size,
+    what `varkoder_amd image` does) and counted + imaged from HBM, every rank its own share at the same time.  Reported:
+    every rank's bytes and milliseconds, and the bytes the static i % world rule would have dealt (not run)."""
+    import torch
+    from varkoder_amd import shard
+    rungs_kbp = [500, 1000, 2000, 5000, 10000, 20000]
+    ns = args.ladder_shard_samples
+    names = sorted("s%03d@%08dK" % (s, kb) for s in range(ns) for kb in rungs_kbp)
+    reads = [max(1, int(n.split("@")[1][:8]) * 1000 // args.readlen) for n in names]
+    rec = 2 * args.readlen + 20
+    weights = [r * rec for r in reads]
+    mine = shard.shard_by_size(weights, rank, world)
+    loads = shard.rank_loads(weights, world)
+    rr = [sum(weights[i] for i in shard.shard_indices(len(names), r, world)) for r in range(world)]
+    err, per_pass = None, []
+    try:
+        offs = np.zeros(len(mine), dtype=np.uint64)
+        lens = np.array([weights[i] for i in mine], dtype=np.uint64)
+        if len(mine) > 1:
+            offs[1:] = np.cumsum((lens[:-1] + np.uint64(15)) // np.uint64(16) * np.uint64(16))
+        total = int(offs[-1] + lens[-1]) if len(mine) else 0
+        buf = torch.empty(((total + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=eng.device)
+        for j, i in enumerate(mine):   # unit i is "sample" (3 << 20) + i of the generator: the same text whoever gets it
+            eng.synth((3 << 20) + i, 1, reads[i], args.readlen, dist=args.dist, out=buf[int(offs[j]):])
+        img, hist, status = eng.fastq_to_images(buf, offs, lens)     # warm-up: workspaces
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001 -- a side measurement: never lose the bench line over it
+        err = repr(e)
+    flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if flag.item() < 0.5:
+        return {"error": err or "another rank failed while making its units"}
+    bad = 0
+    for rep in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img, hist, status = eng.fastq_to_images(buf, offs, lens)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        bad = int((status != 0).sum().item())
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_pass.append([float(x.item()) * 1e3 for x in every])
+    worst = [max(p) for p in per_pass]
+    mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
+    mean = sum(loads) / world
+    return {"units": len(names), "samples": ns, "rungs_kbp": rungs_kbp, "rule": "shard.shard_by_size (longest first, least-loaded rank)",
+            "bytes_by_rank": loads, "max_over_mean_bytes": max(loads) / mean,
+            "ms_by_rank_median_pass": per_pass[mid], "ms_by_rank_all_passes": per_pass,
+            "gbases_per_s": sum(r * args.readlen for r in reads) / (worst[mid] * 1e-3) / 1e9,
+            "round_robin_bytes_by_rank": rr, "round_robin_max_over_mean_bytes": max(rr) / mean,
+            "bad_status_units_this_rank": bad}
 
 
 def config4(args, device_index):
@@ -783,6 +843,11 @@ def main():
         hist = img = None
         torch.cuda.empty_cache()
         e2e_ranks = end_to_end_ranks(eng, args, rank, world, dist, red_dev)
+    lshard = None
+    if world > 1 and args.ladder_shard_samples > 0 and args.k <= 7:   # (every rank takes part)
+        hist = img = None
+        torch.cuda.empty_cache()
+        lshard = ladder_shard(eng, args, rank, world, dist, red_dev)
     count_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     image_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
@@ -847,6 +912,8 @@ def main():
         }
         if e2e_ranks is not None:
             out["end_to_end"] = e2e_ranks
+        if lshard is not None:
+            out["ladder_shard"] = lshard
         if world == 1 and not args.no_config4 and args.k <= 7:
             try:
                 out["config4"] = config4(args, local_rank)

@@ -317,7 +317,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--all-on-device0",
                           "--backend", "gloo", "--steps", "2", "--warmup", "1", "--total-samples", "24", "--pool", "6",
-                          "--reads", "20000", "--e2e-files-per-rank", "3", "--e2e-reads", "5000"],
+                          "--reads", "20000", "--e2e-files-per-rank", "3", "--e2e-reads", "5000", "--ladder-shard-samples", "2"],
                          capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -329,6 +329,9 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     e = d["end_to_end"]                                  # every rank runs the file pipeline on its own files at once
     assert e["all_files_ok"] and e["files_per_rank"] == 3 and e["gbases_per_s"] > 0
     assert all(len(p) == 2 for p in e["passes_s_by_rank"]) and len(e["passes_s_by_rank"]) == 3
+    ls = d["ladder_shard"]                                # units of unequal size (the reference's six-rung ladder), sharded by size
+    assert ls["units"] == 12 and len(ls["bytes_by_rank"]) == 2 and len(ls["ms_by_rank_median_pass"]) == 2
+    assert ls["max_over_mean_bytes"] <= 1.05 < ls["round_robin_max_over_mean_bytes"] and ls["bad_status_units_this_rank"] == 0
     # a launcher that disagrees with --gpus is an error, not a silent one-rank run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"))

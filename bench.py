@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--config4-steps", type=int, default=5)
     ap.add_argument("--no-ladder", action="store_true", help="skip the subsample-ladder leg (N=1 only)")
     ap.add_argument("--ladder-shard-samples", type=int, default=16, help="samples of the N > 1 leg with ladder-shaped (unequal) units; 0 = skip")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run this script again under rocprofv3 --pmc for roofline.traffic "
+                    "(the figure then comes from profiles/traffic_latest.json when that matches the configuration)")
     ap.add_argument("--no-query", action="store_true", help="skip the images -> preprocess -> forward leg (BASELINE configs[4], N=1 only)")
     ap.add_argument("--query-samples", type=int, default=512)
     ap.add_argument("--query-batch", type=int, default=256)
@@ -383,6 +385,59 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res
+
+
+def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=300.0):
+    """HBM bytes per count launch, measured NOW: this script run again as a child of `rocprofv3 --pmc FETCH_SIZE` and of
+    `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md "HBM"), one warm-up and one timed launch
+    of the same configuration, every side leg off.  FETCH_SIZE (KB) x 2 -- gfx950 tallies a wide streaming read at half --
+    + WRITE_SIZE (KB), per dispatch, summed over the count path's kernels (k <= 7: the count kernel alone, as
+    profiles/summarize.py does; k = 8, 9: every vk_bucket_* / vk_quad_* kernel, as profiles/summarize_k9.py does).
+    Returns (bytes or None, note).  The parent must have freed its sample pool: the child allocates its own."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--samples", str(samples), "--pool", str(pool),
+             "--reads", str(args.reads), "--readlen", str(args.readlen), "--k", str(k), "--mapping", mapping, "--dist", str(dist_code),
+             "--parts", str(args.parts), "--no-cpu-baseline", "--no-e2e", "--no-config4", "--no-realistic", "--no-ladder", "--no-query",
+             "--no-live-traffic"]
+    pat = re.compile(r"vk_count_dense_kernel|vk_count_kernel" if k <= 7 else r"vk_bucket\w*|vk_quad\w*")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for drop in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
+        env.pop(drop, None)
+    total = {}
+    with tempfile.TemporaryDirectory(prefix="vk_traffic_", dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            try:
+                r = subprocess.run([prof, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--"] + child,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, cwd="/tmp")
+            except Exception as e:  # noqa: BLE001
+                return None, "rocprofv3 child failed: %r" % (e,)
+            path = None
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if r.returncode != 0 or path is None:
+                return None, "rocprofv3 child: rc %d, %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])
+            per_kernel = {}
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    m = pat.search(row["Kernel_Name"])
+                    if m and row["Counter_Name"] == ctr:
+                        per_kernel.setdefault(m.group(0), []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None, "no %s rows for the count kernels" % ctr
+            total[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
+    return total["FETCH_SIZE"] * 1024 * 2 + total["WRITE_SIZE"] * 1024, \
+        "measured_in_this_run (this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate child processes, the same " \
+        "configuration; FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)"
 
 
 def ladder_shard(eng, args, rank, world, dist, red_dev):
@@ -957,6 +1012,39 @@ def main():
                 out["end_to_end"] = end_to_end(eng, args)
             except Exception as e:  # a side measurement: never lose the bench line over it
                 out["end_to_end"] = {"error": repr(e)}
+        under_profiler = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")) or \
+            any(v.startswith(("ROCPROF", "ROCPROFILER")) for v in os.environ)
+        if world == 1 and not args.no_live_traffic and not under_profiler:
+            # roofline.traffic measured in THIS run (the sample pools of every leg above are freed by now)
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            try:
+                got, note = live_traffic(args, args.k, args.mapping, args.samples, pool, args.dist)
+            except Exception as e:  # noqa: BLE001 -- never lose the bench line over it
+                got, note = None, "live measurement failed: %r" % (e,)
+            out["roofline"]["traffic_from_profile_file"] = out["roofline"]["traffic"]
+            if got is not None:
+                out["roofline"]["traffic"] = got
+                out["roofline"]["traffic_source"] = note
+            else:
+                out["roofline"]["traffic_live_error"] = note
+            c4 = out.get("config4")
+            if isinstance(c4, dict) and "error" not in c4:
+                for dcode in (0, 1, 2):
+                    leg = c4.get("dist%d" % dcode)
+                    if not isinstance(leg, dict) or time.perf_counter() - t0 > 150.0:
+                        continue
+                    try:
+                        got, note = live_traffic(args, 9, "cgr", c4["samples"], c4["samples"], dcode)
+                    except Exception as e:  # noqa: BLE001
+                        got, note = None, "live measurement failed: %r" % (e,)
+                    leg["roofline"]["traffic_from_profile_file"] = leg["roofline"]["traffic"]
+                    if got is not None:
+                        leg["roofline"]["traffic"] = got
+                        leg["roofline"]["traffic_source"] = note
+                    else:
+                        leg["roofline"]["traffic_live_error"] = note
+            out["live_traffic_seconds"] = time.perf_counter() - t0
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -9,7 +9,7 @@ for lib in "$@"; do
   OUT=gpurun_out/r05/k9stage_$tag
   mkdir -p $OUT
   if [ "$lib" = "default" ]; then unset VKIMG_LIB; else export VKIMG_LIB=$lib; fi
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT -o pmc -- python3 bench.py --k 9 --mapping cgr --samples 100 --pool 100 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > $OUT/bench.json 2> $OUT/err.txt
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT -o pmc -- python3 bench.py --k 9 --mapping cgr --samples 100 --pool 100 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-live-traffic > $OUT/bench.json 2> $OUT/err.txt
   python3 - "$OUT" "$tag" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)

@@ -5,7 +5,7 @@ TAG=${1:-k9q}; DIST=${2:-0}
 OUT=gpurun_out/r05/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python3 bench.py --k 9 --mapping cgr --samples 100 --pool 100 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --dist $DIST"
+B="python3 bench.py --k 9 --mapping cgr --samples 100 --pool 100 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-live-traffic --dist $DIST"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/a -o pmc -- $B > $OUT/bench_a.json 2> $OUT/a.err
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/b -o pmc -- $B > $OUT/bench_b.json 2> $OUT/b.err
 python3 - "$OUT" <<'PY'

@@ -6,7 +6,7 @@ TAG=${1:-x}
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder --no-query $PMC_EXTRA"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder --no-query --no-live-traffic $PMC_EXTRA"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT -o p1 -- python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/err1.txt
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o p2 -- python3 bench.py $ARGS > /dev/null 2> $OUT/err2.txt
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH --output-format csv -d $OUT -o p3 -- python3 bench.py $ARGS > /dev/null 2> $OUT/err3.txt

@@ -7,7 +7,7 @@ TAG=${1:-x}
 OUT=gpurun_out/valu_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder --no-query $VALU_EXTRA > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT -o pmc -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-config4 --no-realistic --no-ladder --no-query --no-live-traffic $VALU_EXTRA > $OUT/bench.json 2> $OUT/err.txt
 python3 - "$OUT" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)

@@ -25,8 +25,9 @@
  *   - A context owns device workspaces that grow on demand and is NOT re-entrant: use it
  *     from one thread at a time (one context per worker thread / process is the intended
  *     model: the reference runs one sample per pool worker, image.py:1281-1284).
- *   - k = 8, 9 count through a bucketed two-pass path whose workspace is about twice the
- *     FASTQ bytes of the samples in flight; large batches are processed in sub-batches.
+ *   - k = 8, 9 count through a bucketed two-pass path whose workspace is about half the
+ *     FASTQ bytes of the samples in flight (subsampled counts: about the FASTQ bytes); large
+ *     batches are processed in sub-batches.
  */
 #ifndef VKIMG_H
 #define VKIMG_H

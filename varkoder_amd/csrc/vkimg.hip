@@ -21,9 +21,10 @@
 //     locally from the '@' / '+' framing, so byte ranges are independent;
 //   * k-mer windows are counted forward-strand only into an LDS histogram
 //     (ds_add_u32); the strand merge happens once per sample in K2;
-//   * 4^k u32 > LDS for k = 8, 9: pairs of neighbouring windows are bucketed through wave-private LDS
-//     queues into 16 streams per sample in HBM (one byte per window) and replayed into 4^k/16-bin LDS
-//     histograms (vk_bucket_kernel, vk_bucket_count_kernel).
+//   * 4^k u32 > LDS for k = 8, 9: QUADS of neighbouring windows are bucketed through workgroup-shared LDS
+//     queues into 256 streams per sample in HBM (half a byte per window) and replayed into LDS tables
+//     (vk_bucket_kernel<K, 3>, vk_quad_count_kernel, vk_quad_merge_kernel); subsampled launches: pairs of
+//     windows through wave-private queues into 16 streams (vk_bucket_kernel<K, 1>, vk_bucket_count_kernel).
 //   vk_remap_kernel / vk_preprocess_kernel: `convert`'s remap and the input side of `query`.
 #include <hip/hip_runtime.h>
 

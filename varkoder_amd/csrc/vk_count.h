@@ -2330,7 +2330,26 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
     if (tid < 33) cnt[tid] = 0u;
     __syncthreads();
     auto cls = [](uint32_t blocks) { return blocks ? 32u - static_cast<uint32_t>(__builtin_clz(blocks)) : 0u; };  // 0 .. 32
-    for (uint32_t j = tid; j < njobs; j += 1024) atomicAdd(&cnt[cls(bp.bsize[j])], 1u);
+    // (one LDS atomic per wavefront and class, not per job: the quad route has 256 jobs per sample, nearly all of two or
+    // three classes -- 25600 atomics on three counters were the kernel's 45 us)
+    auto grouped = [&](uint32_t c, bool have, uint32_t* counters) -> uint32_t {   // the job's place among its class: counters[c] moves on by the class's lanes
+        unsigned long long left = __ballot(have);
+        const uint32_t ln = tid & 63u;
+        uint32_t at = 0;
+        while (left != 0ull) {
+            const uint32_t lead = static_cast<uint32_t>(__builtin_ctzll(left));
+            const uint32_t cc = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), static_cast<int>(lead)));
+            const unsigned long long eq = __ballot(have && c == cc) & left;
+            uint32_t base = 0;
+            if (ln == lead) base = atomicAdd(&counters[cc], static_cast<uint32_t>(__builtin_popcountll(eq)));
+            base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), static_cast<int>(lead)));
+            if (have && c == cc) at = base + static_cast<uint32_t>(__builtin_popcountll(eq & ((1ull << ln) - 1ull)));
+            left &= ~eq;
+        }
+        return at;
+    };
+    const uint32_t njobs_up = (njobs + 1023u) / 1024u * 1024u;   // (whole wavefronts take part in the ballots)
+    for (uint32_t j = tid; j < njobs_up; j += 1024) grouped(j < njobs ? cls(bp.bsize[j]) : 0u, j < njobs, cnt);
     __syncthreads();
     if (tid == 0) {
         uint32_t at = 0;
@@ -2340,7 +2359,10 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
         }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < njobs; j += 1024) bp.order[atomicAdd(&first[cls(bp.bsize[j])], 1u)] = j;
+    for (uint32_t j = tid; j < njobs_up; j += 1024) {
+        const uint32_t at = grouped(j < njobs ? cls(bp.bsize[j]) : 0u, j < njobs, first);
+        if (j < njobs) bp.order[at] = j;
+    }
 }
 
 // Pass B, the shipped replay (vk_bucket_count_kernel): ONE LDS add per PAIR.  A pair entry e (LB + 2 bits: the K - 2

@@ -2679,11 +2679,20 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     const uint32_t tid = threadIdx.x;
     const uint32_t job = bp.order[blockIdx.x];  // large streams first (vk_bucket_order_kernel): skewed bases make some buckets several times the average
     const uint32_t s = job / kQuadBuckets, q = job % kQuadBuckets;
+    const uint32_t* first = bp.qfirst + static_cast<uint64_t>(s) * (kQuadBuckets + 1);
+    const uint32_t beg = first[q], end = first[q + 1];
+    {   // a bucket without entries and without listed quads (low-complexity samples: most of their 256) stores zeros and leaves
+        uint32_t any = end - beg;
+        for (uint32_t p = 0; p < bp.parts; ++p) any |= bp.preg_n[(static_cast<uint64_t>(s) * bp.parts + p) * kQuadBuckets + q];
+        if (any == 0u) {
+            uint32_t* out0 = bp.bucket_hist + (static_cast<uint64_t>(s) * kQuadBuckets + q) * (4 * RB);
+            for (uint32_t j = tid; j < 4 * RB; j += 512) out0[j] = 0u;
+            return;
+        }
+    }
     for (uint32_t i = tid; i < 2 * TB; i += 512) tab[i] = 0u;
     for (uint32_t i = tid; i < 4 * RB; i += 512) rr[i] = 0u;
     __syncthreads();
-    const uint32_t* first = bp.qfirst + static_cast<uint64_t>(s) * (kQuadBuckets + 1);
-    const uint32_t beg = first[q], end = first[q + 1];
     const uint32_t* list = bp.qlist + static_cast<uint64_t>(s) * bp.runs_cap;
     const uint8_t* arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
     uint8_t* const t0 = reinterpret_cast<uint8_t*>(tab);

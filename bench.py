@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--config4-samples", type=int, default=100)
     ap.add_argument("--config4-steps", type=int, default=5)
     ap.add_argument("--no-ladder", action="store_true", help="skip the subsample-ladder leg (N=1 only)")
-    ap.add_argument("--ladder-shard-samples", type=int, default=16, help="samples of the N > 1 leg with ladder-shaped (unequal) units; 0 = skip")
+    ap.add_argument("--ladder-shard-samples", type=int, default=256, help="samples of the N > 1 leg with ladder-shaped (unequal) units; 0 = skip")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run this script again under rocprofv3 --pmc for roofline.traffic "
                     "(the figure then comes from profiles/traffic_latest.json when that matches the configuration)")
     ap.add_argument("--no-query", action="store_true", help="skip the images -> preprocess -> forward leg (BASELINE configs[4], N=1 only)")

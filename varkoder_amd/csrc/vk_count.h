@@ -1939,27 +1939,29 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         constexpr uint32_t kIdleSteps = 6;
         uint32_t qstep = 0, idle_left = 0;
         auto step_sync = [&](uint32_t rounds) __attribute__((always_inline)) -> uint32_t {
+#ifndef VK_DIAG_QUAD_NO_IDLE
             if (idle_left != 0u) {   // (wave-uniform and the same in every wave: set from the slot word below)
                 --idle_left;
                 ++qstep;
                 return 1u;
             }
+#endif
             uint32_t* const slots = reinterpret_cast<uint32_t*>(ldsb + kLdsSync);
-            if (lane == 0 && rounds > 1u) atomicMax(&slots[qstep & 1u], rounds);
-            if (lane == 0 && rounds > 0u) slots[4u + (qstep & 1u)] = 1u;   // (a plain store: every writer writes the same)
+            if (lane == 0 && rounds > 0u) atomicMax(&slots[qstep & 1u], rounds);   // (0 stays when no wave appends in this step)
             wg_sync();
             wave_lds_fence();
             uint32_t n = qcnt[q];
             const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
             const bool tight = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[2u + (qstep & 1u)])) != 0;
-            const bool active = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[4u + (qstep & 1u)])) != 0;
+#ifndef VK_DIAG_QUAD_NO_IDLE
+            const bool active = word != 0u;
+#else
+            const bool active = true;
+#endif
             const bool tight_now = __any(n >= 3u * kBlockBytes);
             if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
             if (__any(n >= kBlockBytes)) drain_all(n, n / kBlockBytes);
-            if (tid == 0) {   // (the next step's slots: last read before this step's first barrier)
-                slots[(qstep + 1u) & 1u] = 0u;
-                slots[4u + ((qstep + 1u) & 1u)] = 0u;
-            }
+            if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
             if (lane == 0 && (tight || tight_now)) slots[2u + ((qstep + 1u) & 1u)] = 1u;   // (sticky: only ever set)
             wg_sync();
             ++qstep;
@@ -2096,10 +2098,18 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
             const uint32_t full = append4(x, f);
             if (__any(full != 0u)) hot = true;
+#ifdef VK_DIAG_QUAD_NO_AGG
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (full & (1u << j)) count_quad_direct<K>(hist_s, x[j], 0x55u);
+            }
+#else
             if (__any(full != 0u)) {  // rare: a queue was full, count those quads directly
 #pragma unroll
                 for (int j = 0; j < 4; ++j) count_quads_aggregated<K>(hist_s, (full & (1u << j)) != 0u, x[j]);
             }
+#endif
             partial_store(have0, entry0, place0);
             while (__any(rem != 0u)) {   // reads cut up by N, read ends that meet in one group
                 const bool have = rem != 0u;

@@ -1581,7 +1581,7 @@ constexpr uint32_t kLdsXchg = kLdsQueues + kWaves * kQueues * kQueueBytes;  // u
 constexpr uint32_t kLdsBucketBytes = kLdsXchg + kWaves * 64 * 8;
 constexpr uint32_t kLdsPool = kLdsAbove + 66 * 16;                // u32 [kWaves][2]: the wave's reserve of arena runs, [next, end)
 constexpr uint32_t kPoolRuns = 16;        // runs a wave takes from the arena with one returning atomic
-constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [6]: the quad route's rounds of a step [2], `tight` [2] and "some wave appends" [2], agreed by the workgroup
+constexpr uint32_t kLdsSync = kLdsPool + kWaves * 8;              // u32 [2] (room for 6): the quad route's (rounds | tight << 16) of a step, agreed by the workgroup
 constexpr uint32_t kLdsCntP = kLdsSync + 24;                      // u32 [256]: the quad route's listed quads per bucket (this workgroup's)
 static_assert(kLdsCntP + 256 * 4 <= kLdsQueues, "LDS layout");
 constexpr uint32_t kQuadBuckets = 256;    // the quad route's bucket streams per sample = kWaves * kQueues queues per WORKGROUP
@@ -1931,13 +1931,14 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         // queue of 128 that starts it with at most 31 -- every further drain point costs the workgroup two barriers with a
         // chain of LDS round trips between them (4 points in 10 wave cycles measured).  A wave that finds a queue three
         // quarters full (skewed bases) raises `tight` for good: from the next step on, a drain point before every round
-        // of appends, as many as the busiest wave has.  (slots[step & 1]: rounds, slots[2 + (step & 1)]: tight -- written
-        // before the step's first barrier, read between its barriers: the same in every wave.)
+        // of appends, as many as the busiest wave has.  (slots[step & 1]: the largest (rounds | tight << 16) any wave published
+        // -- an LDS atomicMax before the step's first barrier, read between its barriers: the same in every wave; a wave
+        // publishes the `tight` it knows, so a new one reaches everybody one step later.)
         // A step in which NO wave appends (stretches of homopolymer reads, which the shortcut in `win` counts) makes the
         // next kIdleSteps steps go without a drain point: the queues hold less than a block each then and take a few
         // steps' appends; more than that overflows into the exact direct count.  (An even number: the slots alternate.)
         constexpr uint32_t kIdleSteps = 6;
-        uint32_t qstep = 0, idle_left = 0;
+        uint32_t qstep = 0, idle_left = 0, tight_known = 0;
         auto step_sync = [&](uint32_t rounds) __attribute__((always_inline)) -> uint32_t {
 #ifndef VK_DIAG_QUAD_NO_IDLE
             if (idle_left != 0u) {   // (wave-uniform and the same in every wave: set from the slot word below)
@@ -1947,26 +1948,24 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
 #endif
             uint32_t* const slots = reinterpret_cast<uint32_t*>(ldsb + kLdsSync);
-            if (lane == 0 && rounds > 0u) atomicMax(&slots[qstep & 1u], rounds);   // (0 stays when no wave appends in this step)
+            const uint32_t mine = rounds | (tight_known << 16);
+            if (lane == 0 && mine != 0u) atomicMax(&slots[qstep & 1u], mine);   // (the rounds field stays 0 when no wave appends in this step)
             wg_sync();
             wave_lds_fence();
             uint32_t n = qcnt[q];
             const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(slots[qstep & 1u])));
-            const bool tight = __builtin_amdgcn_readfirstlane(static_cast<int>(slots[2u + (qstep & 1u)])) != 0;
-#ifndef VK_DIAG_QUAD_NO_IDLE
-            const bool active = word != 0u;
-#else
-            const bool active = true;
-#endif
-            const bool tight_now = __any(n >= 3u * kBlockBytes);
+            const bool tight = (word >> 16) != 0u;
+            const uint32_t most = word & 0xFFFFu;
+            if (tight || __any(n >= 3u * kBlockBytes)) tight_known = 1u;
             if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
             if (__any(n >= kBlockBytes)) drain_all(n, n / kBlockBytes);
             if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
-            if (lane == 0 && (tight || tight_now)) slots[2u + ((qstep + 1u) & 1u)] = 1u;   // (sticky: only ever set)
             wg_sync();
             ++qstep;
-            if (!active) idle_left = kIdleSteps;
-            return tight && word > 1u ? word : 1u;
+#ifndef VK_DIAG_QUAD_NO_IDLE
+            if (most == 0u) idle_left = kIdleSteps;
+#endif
+            return tight && most > 1u ? most : 1u;
         };
         // Quads of which only some windows count (~1.5 per read) go to HBM as they are found, into the workgroup's region
         // of their bucket (pass B's job of the bucket reads the regions of the sample's workgroups): the place comes from a

@@ -33,6 +33,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise VkError(VK_EHIP, f"HIP extension not built: {LIB_PATH} is missing "
                                "(run `python -m varkoder_amd.build`); there is no CPU fallback")
+    # PyTorch carries its own HIP runtime (libamdhip64 under torch/lib): it must be the process's one before this library is
+    # loaded, else the loader resolves the library's dependency to the system copy, PyTorch later brings its own, and a
+    # context created here on a stream PyTorch made fails with a HIP runtime error (seen: `build()` then `smoke()` in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32p, u64p, u8p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
     L.vk_abi_version.restype = C.c_int

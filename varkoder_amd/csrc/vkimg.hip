@@ -255,8 +255,8 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
     // 150-base reads over 256 buckets; room for four times that (uniform bases), at least 64
     const uint64_t wg_bytes = maxlen / parts + 64 * kWaves;
     uint32_t pshift = 6;                                   // (a power of two: the place is a shift and an or)
-    while (pshift < 22 && (1ull << pshift) < wg_bytes / 16384 + 64) ++pshift;   // (at most 2^22: a region's byte offset stays below 2^32)
-    if (ctx->spill_misc_cap) pshift = ctx->spill_misc_cap < 22 ? ctx->spill_misc_cap : 22;   // VKIMG_SPILL_MISC_CAP (log2): tests force the region-full fallback
+    while (pshift < 21 && (1ull << pshift) < wg_bytes / 16384 + 64) ++pshift;   // (at most 2^21: a workgroup's 256 regions stay below 2^31 bytes, the size a buffer descriptor takes as an int; what does not fit is counted directly)
+    if (ctx->spill_misc_cap) pshift = ctx->spill_misc_cap < 21 ? ctx->spill_misc_cap : 21;   // VKIMG_SPILL_MISC_CAP (log2): tests force the region-full fallback
     const uint64_t pcap = 1ull << pshift;
     const size_t preg_words = static_cast<size_t>(parts) * kQuadBuckets * (pcap + 1);   // per sample: regions, populations
     const size_t per_sample = static_cast<size_t>(runs) * (kRunBytes + 2 * sizeof(uint32_t)) + (3 * kQuadBuckets + 2) * sizeof(uint32_t) +

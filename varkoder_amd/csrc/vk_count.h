@@ -410,8 +410,17 @@ __device__ __forceinline__ bool repeats_dominate(uint32_t handled, const uint32_
 // this mode while it is not 0).  try_homopolymer: false skips the homopolymer test (the caller passes it while the
 // pieces are tandem repeats, with a look every eighth piece: poly-A is then still exact, as period 1).
 template <int K>
+__device__ __forceinline__ void windows_lds1(uint32_t ch, uint32_t C, uint32_t ok, uint32_t lds_base, uint32_t& probe_addr,
+                                             unsigned long long& probe_mask);   // (defined with the dense kernel below)
+
+// xb: 64 free uint4 slots of this wave in LDS (the dense kernel's exchange buffer, empty while a piece takes the general
+// path), or null.  With it, the lane groups the shortcuts leave over -- the ends of the repeats' reads: one group in ten
+// -- are packed into ONE round of window blocks; without it they take the eight blocks of a whole piece, whose few live
+// lanes all hit the repeat's handful of counters (3.3 of 11.9 ms on (ACGT)n, profiles/ab/r05_low_complexity.txt).
+template <int K>
 __device__ uint32_t windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint32_t ok_in[4], uint32_t* hist, uint32_t lds_base,
-                                    int lane, bool try_homopolymer, uint32_t& probe_addr, unsigned long long& probe_mask) {
+                                    int lane, bool try_homopolymer, uint32_t& probe_addr, unsigned long long& probe_mask,
+                                    uint4* xb = nullptr) {
     const uint32_t v[5] = {ch, C[0], C[1], C[2], C[3]};
     constexpr uint32_t kMask4 = ((1u << (2 * K)) - 1u) << 2;
     // the probe for the next piece: the window that ends at position 40 of every lane, however it gets counted
@@ -435,11 +444,31 @@ __device__ uint32_t windows_lds_hot(uint32_t ch, const uint32_t C[4], const uint
         __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(lds_base + 4u * f)),
                                n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     });
+#ifndef VK_DIAG_HOT_NO_LEFTOVER   // timing only: what the window blocks of the groups the shortcuts left over cost
     if (__any((ok[0] | ok[1] | ok[2] | ok[3]) != 0u)) {
         uint32_t pa;
         unsigned long long pm;
-        windows_lds<K>(ch, C, ok, lds_base, pa, pm);
+        bool packed = false;
+        if (xb != nullptr) {
+            const uint32_t n = (ok[0] != 0u) + (ok[1] != 0u) + (ok[2] != 0u) + (ok[3] != 0u);
+            const uint32_t incl = wave_inclusive_sum(n);
+            const uint32_t tot = lane_bcast(incl, 63);
+            if (tot <= 64u) {
+                uint32_t at = incl - n;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (ok[g] != 0u) xb[at++] = make_uint4(v[g], v[g + 1], ok[g], 0u);
+                wave_lds_fence();
+                uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                if (static_cast<uint32_t>(lane) < tot) e = xb[lane];
+                windows_lds1<K>(e.x, e.y, e.z, lds_base, pa, pm);
+                wave_lds_fence();
+                packed = true;
+            }
+        }
+        if (!packed) windows_lds<K>(ch, C, ok, lds_base, pa, pm);
     }
+#endif
     return repeats_dominate(handled, ok_in) ? 2u : 0u;
 }
 
@@ -1038,7 +1067,10 @@ __device__ __attribute__((noinline)) GeneralState general_piece(uint4 q0, uint4 
     if (st.hot == 0u) windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
     else {
         ++tick;
-        still = windows_lds_hot<K>(ch, lb.C, ok, hist, hist_base, lane, (st.tick >> 31) == 0u || (tick & 7u) == 0u, pa, pm);
+        // (the wave's exchange buffer sits behind the histogram in the dense kernel's LDS block and is empty here: the pending
+        // granules were counted before the call)
+        uint4* const xb = reinterpret_cast<uint4*>(hist + (1u << (2 * K))) + (threadIdx.x >> 6) * 64u;
+        still = windows_lds_hot<K>(ch, lb.C, ok, hist, hist_base, lane, (st.tick >> 31) == 0u || (tick & 7u) == 0u, pa, pm, xb);
     }
     st.hot = (still != 0u || probe_low_complexity(pa, pm, tick)) ? 1u : 0u;
     st.tick = (tick & 0x7FFFFFFFu) | (still == 2u ? 0x80000000u : 0u);
@@ -1195,8 +1227,14 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
     uint32_t* __restrict__ aside, uint32_t aside_cap, uint32_t* __restrict__ aside_n, IndexParams ip) {   // aside[grid * kWaves][aside_cap]: the waves' lists of lanes set aside; aside_n[grid * kWaves]: their lengths
     constexpr uint32_t NCODE = 1u << (2 * K);
     static_assert(NCODE <= kMaxBins, "LDS histogram too large");
-    __shared__ uint32_t hist[NCODE];       // raw-field order, as in vk_count_kernel
-    __shared__ uint4 xbuf[kWaves][64];     // per wave: 64 granules on their way to the heavy stage
+    // (one block, so that general_piece finds the exchange buffers behind the histogram it is handed)
+    struct DenseLds {
+        uint32_t hist[NCODE];      // raw-field order, as in vk_count_kernel
+        uint4 xbuf[kWaves][64];    // per wave: 64 granules on their way to the heavy stage
+    };
+    __shared__ __attribute__((aligned(16))) DenseLds dlds;
+    uint32_t (&hist)[NCODE] = dlds.hist;
+    uint4 (&xbuf)[kWaves][64] = dlds.xbuf;
 
     const uint32_t unit = blockIdx.x;
     const uint32_t smp = unit / parts;

@@ -387,7 +387,7 @@ def end_to_end_ranks(eng, args, rank, world, dist, red_dev):
     return res
 
 
-def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=300.0):
+def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=180.0):
     """HBM bytes per count launch, measured NOW: this script run again as a child of `rocprofv3 --pmc FETCH_SIZE` and of
     `rocprofv3 --pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md "HBM"), one warm-up and one timed launch
     of the same configuration, every side leg off.  FETCH_SIZE (KB) x 2 -- gfx950 tallies a wide streaming read at half --
@@ -1031,7 +1031,7 @@ def main():
             else:
                 out["roofline"]["traffic_live_error"] = note
             c4 = out.get("config4")
-            if isinstance(c4, dict) and "error" not in c4:
+            if got is not None and isinstance(c4, dict) and "error" not in c4:   # (a profiler that cannot run here is not asked six more times)
                 for dcode in (0, 1, 2):
                     leg = c4.get("dist%d" % dcode)
                     if not isinstance(leg, dict) or time.perf_counter() - t0 > 150.0:

@@ -480,14 +480,19 @@ def ladder_shard(eng, args, rank, world, dist, red_dev):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        img, hist, status = eng.fastq_to_images(buf, offs, lens)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        bad = int((status != 0).sum().item())
+        try:   # (a rank that fails here still takes part in the pass's collectives: its time reads NaN)
+            img, hist, status = eng.fastq_to_images(buf, offs, lens)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            bad = int((status != 0).sum().item())
+        except Exception as e:  # noqa: BLE001
+            err, dt = repr(e), float("nan")
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         per_pass.append([float(x.item()) * 1e3 for x in every])
+    if any(x != x for p in per_pass for x in p):
+        return {"error": err or "another rank failed in a timed pass", "ms_by_rank_all_passes": per_pass}
     worst = [max(p) for p in per_pass]
     mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
     mean = sum(loads) / world

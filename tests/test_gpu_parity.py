@@ -456,9 +456,9 @@ def test_giant_sample_ranges_sum_to_the_whole(engines):
     assert np.array_equal(total, want)
 
 
-@pytest.mark.parametrize("k,mapping", [(8, "cgr"), (8, "varKode"), (9, "cgr"), (9, "varKode")])
+@pytest.mark.parametrize("k,mapping", [(7, "cgr"), (7, "varKode"), (8, "cgr"), (8, "varKode"), (9, "cgr"), (9, "varKode")])
 def test_large_image_order_statistics_by_counting(engines, k, mapping):
-    """Large images take vk_image_count_kernel (counted ranks + a sorted list of outliers) with
+    """Images of k >= 7 take vk_image_count_kernel (counted ranks + a sorted list of outliers) with
     vk_image_kernel's sort as the fallback: every regime against the oracle's sort."""
     import torch
     eng = engines(k, mapping)
@@ -480,6 +480,33 @@ def test_large_image_order_statistics_by_counting(engines, k, mapping):
     for i, name in enumerate(names):
         want = oracle.image(oracle.strand_merge(fwd[i], k), k, lut, s * s)
         assert np.array_equal(img[i].ravel(), want), name
+
+
+@pytest.mark.parametrize("mapping", ("varKode", "cgr"))
+def test_k7_images_by_counting_equal_the_sorted_ones(monkeypatch, mapping):
+    """Round 5 moved k = 7 images from the LDS sort to the counting kernel: both routes on histograms of real
+    shape (counts of synthetic samples of very different depth, a poly-A sample, an empty one) against the oracle."""
+    import torch
+    from varkoder_amd.engine import ImageEngine
+    from fastq_cases import random_fastq, rec
+    rng = np.random.default_rng(77)
+    blobs = [random_fastq(rng, nrec=nrec) for nrec in (3, 400, 20000)]
+    blobs.append(b"".join(rec("a%d" % i, "A" * 150) for i in range(5000)))
+    blobs.append(b"".join(rec("t%d" % i, "ACGTTGCAAC" * 15) for i in range(5000)))
+    blobs.append(rec("n", "N" * 100))
+    hist = np.stack([oracle.count_fastq(b, 7)[0] for b in blobs]).astype(np.uint32)
+    hist[2] *= 40000                                       # counts far beyond 16 bits: listed, not counted
+    lut, s = pixel_lut(7, mapping), side(7, mapping)
+    want = [oracle.image(oracle.strand_merge(h, 7), 7, lut, s * s) for h in hist]
+    for sort_only in ("0", "1"):
+        monkeypatch.setenv("VKIMG_IMAGE_SORT_ONLY", sort_only)
+        eng = ImageEngine(k=7, mapping=mapping, device=0)
+        try:
+            img = eng.images(torch.from_numpy(hist.view(np.int32)).cuda()).cpu().numpy()
+        finally:
+            eng.close()
+        for i in range(len(blobs)):
+            assert np.array_equal(img[i].ravel(), want[i]), (sort_only, i)
 
 
 # ---- the sequence-only heavy stage of the k <= 7 kernel (vk_count_dense_kernel) --------------------

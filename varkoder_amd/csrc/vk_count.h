@@ -1694,6 +1694,38 @@ __device__ __attribute__((noinline)) void count_quads_aggregated(uint32_t* hist_
     if ((left >> lane_now()) & 1ull) count_quad_direct<K>(hist_s, key, 0x55u);
 }
 
+// A lane group (codes [lo | hi], OK string okg) of a low-complexity stretch, before its quads are appended: quads that
+// SEVERAL lanes hold alike -- whole or not: the read ends the repeat shortcut leaves over are the same few quads in a
+// fifth of the lanes -- are counted here, once per class with their number, and taken out of okg; what one lane holds
+// alone goes on to the queues.  (Sent there, 16 waves x 64 lanes fill the handful of queues of those quads within a
+// round: returning LDS atomics on one counter, a drain point per round, and the overflow counted anyway.)  All lanes call it.
+template <int K>
+__device__ __attribute__((noinline)) uint32_t count_hot_quads(uint32_t* hist_s, uint32_t lo, uint32_t hi, uint32_t okg) {
+    const uint64_t v = (static_cast<uint64_t>(hi) << 32) | lo;
+#pragma nounroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t okb = (okg >> (8u * j)) & 0x55u;
+        const uint32_t o = (32u - 2u * (K - 1) + 8u * j) & 63u;   // bit offset of the quad's first base in [lo | hi]
+        const uint32_t key = (static_cast<uint32_t>(v >> o) & ((1u << (2 * K + 6)) - 1u)) | (okb << 24);
+        unsigned long long left = __ballot(okb != 0u);
+        uint32_t alone = 0;
+        for (int t = 0; t < 6 && left != 0ull && alone < 2u; ++t) {
+            const int src = __builtin_ctzll(left);
+            const uint32_t first = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), src));
+            const unsigned long long eq = __ballot(okb != 0u && key == first) & left;
+            const uint32_t n = static_cast<uint32_t>(__builtin_popcountll(eq));
+            left &= ~eq;
+            if (n == 1u) {   // ordinary reads among the repeats: two of those and the rest is left alone
+                ++alone;
+                continue;
+            }
+            if (lane_now() == static_cast<uint32_t>(src)) count_quad_direct<K>(hist_s, first & 0xFFFFFFu, first >> 24, n);
+            if ((eq >> lane_now()) & 1ull) okg &= ~(0x55u << (8u * j));
+        }
+    }
+    return okg;
+}
+
 __device__ __forceinline__ uint32_t quad_bcast0(uint32_t x) {  // value of lane (lane & ~3)
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(x), 0x00, 0xF, 0xF, true));
 }
@@ -2104,7 +2136,22 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
         };
         // The quad route's append stage of one lane group: its four quads (windows ending at 4j .. 4j + 3).
+        uint32_t hotq_rest = 0;   // rounds of a low-complexity stretch that go without count_hot_quads (wave-uniform)
         auto append_quads = [&](uint32_t lo, uint32_t hi, uint32_t okg) __attribute__((always_inline)) {
+#ifndef VK_DIAG_HOT_NO_CLASSES
+            if (hot) {   // (wave-uniform, rare)
+                // a call that takes out fewer than half of the groups it is shown (repeats with ordinary reads among
+                // them: every group of those comes by here) buys the next 32 rounds a rest
+                if (hotq_rest != 0u) --hotq_rest;
+                else {
+                    const uint32_t was = okg;
+                    okg = count_hot_quads<K>(hist_s, lo, hi, okg);
+                    const uint32_t shown = static_cast<uint32_t>(__builtin_popcountll(__ballot(was != 0u)));
+                    const uint32_t taken = static_cast<uint32_t>(__builtin_popcountll(__ballot(okg != was)));
+                    if (2u * taken < shown) hotq_rest = 32u;
+                }
+            }
+#endif
             // bit 8j of `all` / `some`: all four / some but not all of the windows ending at 4j .. 4j + 3 count
             const uint32_t p2 = okg & (okg >> 2), o2 = okg | (okg >> 2);
             const uint32_t all = p2 & (p2 >> 4) & 0x01010101u;

@@ -312,7 +312,7 @@ int launch_spill_quad(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_off
         VK_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL((vk_quad_count_kernel<K>), dim3(n * kQuadBuckets), dim3(512), 0, ctx->stream, bp);
         VK_HIP(ctx, hipGetLastError());
-        hipLaunchKernelGGL((vk_quad_merge_kernel<K>), dim3(n * (NCODE / 256)), dim3(256), 0, ctx->stream, bp, hist0);
+        hipLaunchKernelGGL((vk_quad_merge_kernel<K>), dim3(n * (NCODE / kMergeTile)), dim3(256), 0, ctx->stream, bp, hist0);
         VK_HIP(ctx, hipGetLastError());
     }
     return VK_OK;

@@ -2492,6 +2492,13 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     constexpr uint32_t M = ((1u << (LB + 1)) - 1u) << 2;
     uint8_t* const h0 = reinterpret_cast<uint8_t*>(hist);
     auto tally2 = [&](uint32_t w) __attribute__((always_inline)) {  // two entries: the halves of a dword
+#ifdef VK_DIAG_QB_NOATOMIC       // timing only
+        asm volatile("" :: "v"(w));
+        return;
+#endif
+#ifdef VK_DIAG_QB_NOCONFLICT     // timing only: every lane its own bank
+        w = (w & ~0x03FF03FFu) | (((tid & 63u) | ((tid & 15u) << 6)) * 0x00010001u);   // bits 0..5 and bits 4..9 both name the lane
+#endif
         const uint32_t t0 = (w >> (LB + 1)) & 1u, t1 = (w >> (LB + 17)) & 1u;
         atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w << 2) & M)), __umul24(t0, 0xFFFFu) + 1u);
         atomicAdd(reinterpret_cast<uint32_t*>(h0 + ((w >> 14) & M)), __umul24(t1, 0xFFFFu) + 1u);

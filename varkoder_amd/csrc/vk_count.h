@@ -1739,6 +1739,10 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
     const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
     uint32_t* __restrict__ hist_out, uint32_t* __restrict__ wavephase, BucketParams bp, SubParams sp, PackParams pk) {
     constexpr bool SUB = MODE == 1, STREAM = MODE == 2, QUAD = MODE == 3;
+#ifndef VK_QUAD_CAP_BYTES
+#define VK_QUAD_CAP_BYTES kQueueBytes   // (timing experiments: a smaller capacity in the same 256-byte slots)
+#endif
+    constexpr uint32_t kCap = QUAD ? static_cast<uint32_t>(VK_QUAD_CAP_BYTES) : kQueueBytes;
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr uint32_t NQ = QUAD ? kQuadBuckets : kQueues;   // bucket streams per sample
     constexpr uint32_t LB = 2 * K - 4;               // bits of an entry that come from the shared prefix
@@ -1881,7 +1885,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
     auto maybe_drain = [&](uint32_t at_least) __attribute__((always_inline)) {
         wave_lds_fence();
         uint32_t n = qcnt[q];
-        if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
+        if (n > kCap) n = kCap;  // appends beyond the capacity were counted directly
         if (__any(n >= at_least)) drain_all(n, n / kBlockBytes);
     };
 
@@ -1927,7 +1931,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             }
             uint32_t a0, a1, a2, a3;
             unsigned long long m0, m1, m2, m3, k0, k1, k2, k3;
-            const uint32_t cap = kQueueBytes;
+            const uint32_t cap = kCap;
             const unsigned long long exec_in = __builtin_amdgcn_read_exec();  // put back behind the block, whatever it was
             asm volatile(
                 "v_cmp_ne_u32_e64 %[m0], 0, %[f0]\n\t"
@@ -2027,7 +2031,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
             const bool tight = (word >> 16) != 0u;
             const uint32_t most = word & 0xFFFFu;
             if (tight || __any(n >= 3u * kBlockBytes)) tight_known = 1u;
-            if (n > kQueueBytes) n = kQueueBytes;  // appends beyond the capacity were counted directly
+            if (n > kCap) n = kCap;  // appends beyond the capacity were counted directly
             if (__any(n >= kBlockBytes)) drain_all(n, n / kBlockBytes);
             if (tid == 0) slots[(qstep + 1u) & 1u] = 0u;   // (the next step's slot: last read before this step's first barrier)
             wg_sync();
@@ -2393,7 +2397,7 @@ __global__ __launch_bounds__(kCountThreads, MODE == 1 ? 4 : VK_K1_OCC) void vk_b
         // the end of the range: full blocks to the arena, the rest of every queue counted directly, runs closed
         wave_lds_fence();
         uint32_t n = qcnt[q];
-        if (n > kQueueBytes) n = kQueueBytes;
+        if (n > kCap) n = kCap;
         drain_all(n, n / kBlockBytes);
         n = qcnt[q];
         const uint16_t* q16 = reinterpret_cast<const uint16_t*>(qdata);

@@ -2510,9 +2510,10 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_kernel(BucketPa
     const uint32_t g = tid & 255u;   // 256 threads per run: the 16-byte granule this thread reads (four per block)
     const uint32_t grp = tid >> 8;   // four runs at a time
     auto fetch = [&](uint32_t i, uint32_t n, uint4& v) __attribute__((always_inline)) -> bool {
-        const uint32_t item = i < n ? list[i] : 0u;
+        const uint32_t item = i < n ? list[i] : 0u;   // (behind the list's end: run 0, nothing taken)
         const bool have = i < n && (g >> 2) < (item >> 24);
-        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
+        // (unconditional, a thread without a granule re-reads the run's first: in a branch every load waited out the one before -- vk_quad_count_kernel)
+        v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + (have ? g : 0u));
         return have;
     };
     uint32_t tallied = 0;            // entries this thread replayed
@@ -2626,9 +2627,10 @@ __global__ __launch_bounds__(kCountThreads) void vk_bucket_count_wide_kernel(Buc
     const uint32_t g = tid & 255u;   // 256 threads per run: the 16-byte granule this thread reads (four per block)
     const uint32_t grp = tid >> 8;   // four runs at a time
     auto fetch = [&](uint32_t i, uint32_t n, uint4& v) __attribute__((always_inline)) -> bool {
-        const uint32_t item = i < n ? list[i] : 0u;
+        const uint32_t item = i < n ? list[i] : 0u;   // (behind the list's end: run 0, nothing taken)
         const bool have = i < n && (g >> 2) < (item >> 24);
-        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
+        // (unconditional, a thread without a granule re-reads the run's first: in a branch every load waited out the one before -- vk_quad_count_kernel)
+        v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + (have ? g : 0u));
         return have;
     };
     auto tally4 = [&](const uint4& v) __attribute__((always_inline)) {
@@ -2788,7 +2790,8 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     const uint32_t beg = first[q], end = first[q + 1];
     {   // a bucket without entries and without listed quads (low-complexity samples: most of their 256) stores zeros and leaves
         uint32_t any = end - beg;
-        for (uint32_t p = 0; p < bp.parts; ++p) any |= bp.preg_n[(static_cast<uint64_t>(s) * bp.parts + p) * kQuadBuckets + q];
+        if (any == 0u)   // (only then: a population per part is a chain of loads a job with runs should not wait for)
+            for (uint32_t p = 0; p < bp.parts; ++p) any |= bp.preg_n[(static_cast<uint64_t>(s) * bp.parts + p) * kQuadBuckets + q];
         if (any == 0u) {
             uint32_t* out0 = bp.bucket_hist + (static_cast<uint64_t>(s) * kQuadBuckets + q) * (4 * RB);
             for (uint32_t j = tid; j < 4 * RB; j += 512) out0[j] = 0u;
@@ -2797,9 +2800,15 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     }
     for (uint32_t i = tid; i < 2 * TB; i += 512) tab[i] = 0u;
     for (uint32_t i = tid; i < 4 * RB; i += 512) rr[i] = 0u;
-    __syncthreads();
     const uint32_t* list = bp.qlist + static_cast<uint64_t>(s) * bp.runs_cap;
     const uint8_t* arena = bp.arena + static_cast<uint64_t>(s) * bp.runs_cap * kRunBytes;
+    // The job's run list goes through LDS, kListChunk items at a time: read from memory where it is needed, an item came
+    // back behind every load issued before it (one counter, in order) -- each batch of run loads waited out the batch
+    // before it, and a memory round trip with nothing but four list words in flight followed.
+    constexpr uint32_t kListChunk = 1024;
+    __shared__ uint32_t litems[kListChunk];
+    for (uint32_t i = tid; i < kListChunk && beg + i < end; i += 512) litems[i] = list[beg + i];
+    __syncthreads();
     uint8_t* const t0 = reinterpret_cast<uint8_t*>(tab);
     uint8_t* const t1 = reinterpret_cast<uint8_t*>(tab + TB);
     auto tally2 = [&](uint32_t w) __attribute__((always_inline)) {  // two entries: the halves of a dword
@@ -2817,25 +2826,36 @@ __global__ __launch_bounds__(512) void vk_quad_count_kernel(BucketParams bp) {
     // a run = 256 granules of 16 bytes: half of the workgroup per run (g = the thread's granule), two runs at a time,
     // eight loads in flight per thread
     const uint32_t g = tid & 255u, half = tid >> 8;
-    auto fetch = [&](uint32_t i, uint4& v) __attribute__((always_inline)) -> bool {
-        const uint32_t item = i < end ? list[i] : 0u;
-        const bool have = i < end && (g >> 2) < (item >> 24);
-        if (have) v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(item & 0xFFFFFFu) * kRunBytes) + g);
-        return have;
-    };
-    {
+    for (uint32_t cbeg = beg; cbeg < end; cbeg += kListChunk) {
+        const uint32_t cn = end - cbeg < kListChunk ? end - cbeg : kListChunk;   // items of this chunk: litems[0 .. cn)
+        if (cbeg != beg) {   // (a job of more than kListChunk runs: skewed or low-complexity samples)
+            __syncthreads();
+            for (uint32_t i = tid; i < cn; i += 512) litems[i] = list[cbeg + i];
+            __syncthreads();
+        }
+        // (the load is unconditional -- a thread without a granule re-reads the first one of the run, or of run 0 behind the
+        // list's end: inside a branch every load came out with an `s_waitcnt vmcnt(0)` in front of it, ONE load in flight per
+        // wave, and the kernel ran at the latency of its stream: 1.93 ms whether or not it counted anything)
+        auto fetch = [&](uint32_t i, uint4& v) __attribute__((always_inline)) -> bool {
+            const uint32_t item = litems[i < cn ? i : 0u];
+            const bool in = i < cn;
+            const bool have = in && (g >> 2) < (item >> 24);
+            const uint32_t run = in ? (item & 0xFFFFFFu) : 0u;
+            v = *(reinterpret_cast<const uint4*>(arena + static_cast<uint64_t>(run) * kRunBytes) + (have ? g : 0u));
+            return have;
+        };
         uint4 a0, a1, a2, a3, b0, b1, b2, b3;
         bool ha0, ha1, ha2, ha3, hb0, hb1, hb2, hb3;
-        uint32_t i = beg + half;
+        uint32_t i = half;
         ha0 = fetch(i, a0); ha1 = fetch(i + 2, a1); ha2 = fetch(i + 4, a2); ha3 = fetch(i + 6, a3);
-        while (i < end) {
+        while (i < cn) {
             hb0 = fetch(i + 8, b0); hb1 = fetch(i + 10, b1); hb2 = fetch(i + 12, b2); hb3 = fetch(i + 14, b3);
             if (ha0) tally4(a0);
             if (ha1) tally4(a1);
             if (ha2) tally4(a2);
             if (ha3) tally4(a3);
             i += 8;
-            if (i >= end) break;
+            if (i >= cn) break;
             ha0 = fetch(i + 8, a0); ha1 = fetch(i + 10, a1); ha2 = fetch(i + 12, a2); ha3 = fetch(i + 14, a3);
             if (hb0) tally4(b0);
             if (hb1) tally4(b1);

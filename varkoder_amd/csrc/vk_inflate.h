@@ -574,19 +574,37 @@ struct GzRes {
     uint32_t rounds;  // (diagnostics) rounds it took
 };
 
-// The ring's tokens -> text.  Output offsets by prefix sum; then rounds: the longest run of tokens
-// whose sources are already written goes out in parallel, the stores are awaited, and so on.
+// The ring's tokens -> text, 64 output positions (a SLAB) at a time, in order.  Output offsets by prefix sum; a position's
+// token is the rank of its bit among the token starts (sixteen 64-bit masks per 1024 positions, one LDS atomic per token);
+// its element is the token's literal, or the element `dist` positions back (the match's own output taken modulo dist),
+// which is found
+//   * in `hist`, the last 1024 elements this wavefront produced, kept in LDS (u16) -- nearly every source at zlib's fast
+//     levels, whose matches reach a few hundred bytes back;
+//   * in this very slab: the lanes wait their turn (a lane's source lane is below it; the lowest waiting lane's source is
+//     always final, so every pass of the loop settles at least one lane; chains are a few links long);
+//   * further back: in the text in memory, behind a wait for this wavefront's outstanding stores, or -- SYM, before the
+//     chunk -- as a mark for the unknown window.
+// Rounds 2-4 wrote "the longest run of tokens whose sources are already written" per round, each round one wait for its
+// loads and one for its stores: at zlib level 1 a round was SEVEN tokens (every match leans on the one before it) and the
+// resolver 59 % of the chunk decoder's time (tools/gz_stamps.py, profiles/ab/r05_gz_resolver.txt).
+// hist_from: this wavefront's output from this position on went through `hist` (a stored block goes around it).
 // SYM = false: text bytes; SYM = true: u16 elements, positions before the chunk stand for the unknown window.
+typedef __attribute__((address_space(3))) uint16_t* GzHistP;
+#ifndef VK_GZ_HIST
+#define VK_GZ_HIST 512
+#endif
+constexpr uint32_t kGzHist = VK_GZ_HIST;   // elements of history in LDS
+constexpr uint32_t kGzBatch = kGzHist / 128;   // slabs resolved together: half of hist
 template <bool SYM>
-__device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint64_t cap_, uint64_t opos_, uint32_t nring_,
-                                                       uint32_t window_open_, uint64_t member_text0_) {
+__device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hist, void* out_, uint64_t cap_, uint64_t opos_, uint32_t nring_,
+                                                       uint32_t window_open_, uint64_t member_text0_, uint64_t hist_from_) {
     const int lane = gz_lane();
     typedef __attribute__((address_space(1))) uint8_t* G8;
     typedef __attribute__((address_space(1))) uint16_t* G16;
     const uint64_t out_addr = gz_uni64(reinterpret_cast<uint64_t>(out_));
     G8 out8 = reinterpret_cast<G8>(out_addr);
     G16 out16 = reinterpret_cast<G16>(out_addr);
-    const uint64_t cap = gz_uni64(cap_), member_text0 = gz_uni64(member_text0_);
+    const uint64_t cap = gz_uni64(cap_), member_text0 = gz_uni64(member_text0_), hist_from = gz_uni64(hist_from_);
     const uint32_t nring = gz_uni(nring_);
     const bool window_open = gz_uni(window_open_) != 0u;
     uint32_t st = 0, rounds = 0;
@@ -597,6 +615,10 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
     auto store_elem = [&](uint64_t p, uint32_t v) {
         if (SYM) out16[p] = static_cast<uint16_t>(v);
         else out8[p] = static_cast<uint8_t>(v);
+    };
+    auto lds_fence = [&]() {   // LDS writes of this wave before, LDS reads of this wave behind
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the ring was written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
@@ -626,84 +648,127 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
         const uint64_t reach = window_open ? off + 32768u : off - member_text0;
         const bool bad = live && is_match && (dist == 0u || dist > reach || dist > 32768u);
         if (__any(bad)) { st |= kGzBadData; break; }
-        // Source ends (exclusive) and rounds.  A round writes the elements of tokens [done, upto) with the whole
-        // wave, lane = output position, 1024 positions at a time: the tokens that begin there set their bits in
-        // sixteen 64-bit masks (one LDS atomic), a position's token is the rank of its bit, and since every
-        // source of a round lies below the frontier the loads are independent of its stores: four in flight.
-        const long long src0 = static_cast<long long>(off) - static_cast<long long>(dist);
-        const long long src_end = is_match ? src0 + static_cast<long long>(len < dist ? len : dist) : 0;
         const uint32_t start = incl - len;                  // relative to `base`
         L->start[lane] = start;
-        long long frontier = static_cast<long long>(base);  // everything below is written and visible
-        uint32_t done = 0;                                  // tokens [0, done) of this group are out
-        uint32_t r0 = 0;                                    // = start of token `done`
-        const uint32_t ngroup = nring - t0 < 64 ? nring - t0 : 64;
+        const uint32_t base_lo = static_cast<uint32_t>(base) & (kGzHist - 1u);
+        // the lowest position (relative to base, <= 0) that went through hist
+        const long long hf = static_cast<long long>(hist_from) - static_cast<long long>(base);
+        const int32_t hist_rel = hf < -100000ll ? -100000 : static_cast<int32_t>(hf);
         GZ_T(q1);
         GZ_ADD(qa, q0, q1);
-        while (done < ngroup) {
+        for (uint32_t c0 = 0; c0 < total; c0 += 1024) {
             GZ_T(q1);
-            const bool ready = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < ngroup &&
-                               (!is_match || src_end <= frontier);
-            const unsigned long long rb = __ballot(ready);
-            // first lane >= done that is not ready
-            const unsigned long long notready = ~rb & (~0ull << done);
-            uint32_t upto = notready ? static_cast<uint32_t>(__builtin_ctzll(notready)) : 64u;
-            if (upto > ngroup) upto = ngroup;
-            const bool mine = static_cast<uint32_t>(lane) >= done && static_cast<uint32_t>(lane) < upto;
-            const uint32_t r1 = upto < ngroup ? gz_uni(__shfl(start, static_cast<int>(upto))) : total;
-            for (uint32_t s0 = r0; s0 < r1; s0 += 1024) {
-                if (lane < 16) L->mask[lane] = 0ull;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t rel = start - s0;
-                if (mine && start >= s0 && rel < 1024u) __hip_atomic_fetch_or(&L->mask[rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                // tokens of the round that begin before s0 (the first of them owns the positions up to the first bit)
-                uint32_t before = done + static_cast<uint32_t>(__popcll(__ballot(mine && start < s0)));
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t nwin = (((r1 - s0 < 1024u ? r1 - s0 : 1024u) + 63u) >> 6);
-                GZ_T(q2);
-                GZ_ADD(qb, q1, q2);
-                for (uint32_t w0 = 0; w0 < nwin; w0 += 4) {
-                    // Four windows at a time, in stages without a branch around any memory operation (the
-                    // compiler waits for a load at the end of the branch it sits in): masks, owners, the
-                    // owners' tokens and offsets, sources, stores.  Positions past the round's end and
-                    // literals load a harmless element (position 0) and are masked out afterwards.
-                    unsigned long long m[4];
-                    uint32_t own[4], tk[4], ts[4], raw[4];
-                    long long src[4];
+            if (lane < 16) L->mask[lane] = 0ull;
+            lds_fence();
+            const uint32_t rel = start - c0;
+            if (live && start >= c0 && rel < 1024u) __hip_atomic_fetch_or(&L->mask[rel >> 6], 1ull << (rel & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            uint32_t before = static_cast<uint32_t>(__popcll(__ballot(live && start < c0)));   // tokens that begin before the chunk
+            lds_fence();
+            const uint32_t cend = total - c0 < 1024u ? total : c0 + 1024u;
+            GZ_T(q2);
+            GZ_ADD(qb, q1, q2);
+            // Up to eight slabs (a batch) at a time, in two passes.  Pass 1, per slab: the positions' tokens and sources; an
+            // element that is a literal, or whose source lies before the batch and in hist, is final at once; a source before
+            // hist is ASKED FOR from the text in memory (or is a mark for the unknown window); a source inside the batch is
+            // left as a reference.  All the batch's loads are in flight before anything waits for one -- a wait for a load is a
+            // wait for every older store of the wave (vmcnt counts in order), and pass 1 is what passes the time the last
+            // batch's stores need.  Pass 2, per slab in order: references into earlier slabs from hist, chains inside the slab
+            // in registers, the slab into hist and out to the text.
+            for (uint32_t b0 = c0; b0 < cend; b0 += 64u * kGzBatch) {
+                const uint32_t nslab = (cend - b0 < 64u * kGzBatch ? cend - b0 + 63u : 64u * kGzBatch) >> 6;
+                const int32_t lo_ring = static_cast<int32_t>(b0) - static_cast<int32_t>(kGzHist);
+                const int32_t ring_lo = lo_ring > hist_rel ? lo_ring : hist_rel;    // what hist holds of the positions before b0
+                uint32_t val[kGzBatch], raw[kGzBatch];
+                int32_t ref[kGzBatch];      // >= 0: the element of that position of this batch (relative to base); kFinal; kFar: raw[k]
+                constexpr int32_t kFinal = -1, kFar = -2;
+                bool any_far = false;
+                __builtin_amdgcn_s_waitcnt(0x0F7F);   // vmcnt(15): the stores of everything behind hist have reached L2
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) m[u] = L->mask[w0 + u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned long long mu = gz_uni64(m[u]);
-                        own[u] = before + static_cast<uint32_t>(__popcll(mu & (~0ull >> (63 - lane)))) - 1u;  // the last token that begins at or before e
-                        before += static_cast<uint32_t>(__popcll(mu));
+                for (uint32_t k = 0; k < kGzBatch; ++k) {
+                    val[k] = 0u;
+                    raw[k] = 0u;
+                    ref[k] = kFinal;
+                    if (k < nslab) {
+                        const uint32_t s0 = b0 + 64u * k;
+                        const unsigned long long m = gz_uni64(L->mask[(s0 - c0) >> 6]);
+                        const uint32_t e = s0 + static_cast<uint32_t>(lane);   // relative to `base`
+                        const bool act = e < total;
+                        const uint32_t own = before + static_cast<uint32_t>(__popcll(m & (~0ull >> (63 - lane)))) - 1u;  // the last token that begins at or before e
+                        before += static_cast<uint32_t>(__popcll(m));
+                        const uint32_t tk = L->ring[t0 + (own & 63u)], ts = L->start[own & 63u];
+                        const bool mt = act && (tk >> 31) != 0u;
+                        const uint32_t d = (tk >> 9) & 0xFFFFu;
+                        uint32_t i = e - ts;
+                        if (__any(mt && i >= d)) {   // a match that overlaps its own output: the source taken modulo the distance
+                            if (mt && i >= d) i = d == 1u ? 0u : i % d;
+                        }
+                        const int32_t src = static_cast<int32_t>(ts + i) - static_cast<int32_t>(d);   // relative to base, below ts
+                        uint32_t v = tk & 0xFFu;
+                        const bool inb = mt && src >= static_cast<int32_t>(b0);
+                        const bool ring = mt && !inb && src >= ring_lo;
+                        const bool far = mt && !inb && !ring;
+                        if (ring) v = hist[(base_lo + static_cast<uint32_t>(src)) & (kGzHist - 1u)];
+                        const long long asrc = static_cast<long long>(base) + src;
+                        if (far && SYM && asrc < 0) v = 0x8000u | static_cast<uint32_t>(asrc + 32768);
+                        const bool ask = far && asrc >= 0;
+                        any_far = any_far || __any(ask);
+                        val[k] = ask ? static_cast<uint32_t>(src) : v;   // (a source in memory: its position, until the element is there)
+                        ref[k] = inb ? src : (ask ? kFar : kFinal);
                     }
+                }
+                if (any_far) {
+                    // (wave-uniform.  The batch's loads and ONE wait behind them, in one asm statement -- its outputs are good when
+                    // it ends, whatever the compiler does with them next: hipcc waits for a relaxed atomic load, and for a plain
+                    // load inside a branch, right behind it, which made a memory round trip of every one of these)
+                    static_assert(kGzBatch == 4, "the asm statement below names four loads");
+                    uint64_t a[kGzBatch];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        tk[u] = L->ring[t0 + own[u]];
-                        ts[u] = L->start[own[u]];
+                    for (uint32_t k = 0; k < kGzBatch; ++k) {
+                        const long long p = ref[k] == kFar ? static_cast<long long>(base) + static_cast<int32_t>(val[k]) : 0ll;
+                        a[k] = out_addr + static_cast<uint64_t>(p) * (SYM ? 2u : 1u);
                     }
+                    if (SYM)
+                        asm volatile("global_load_ushort %0, %4, off sc0\n\tglobal_load_ushort %1, %5, off sc0\n\t"
+                                     "global_load_ushort %2, %6, off sc0\n\tglobal_load_ushort %3, %7, off sc0\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3])
+                                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+                    else
+                        asm volatile("global_load_ubyte %0, %4, off sc0\n\tglobal_load_ubyte %1, %5, off sc0\n\t"
+                                     "global_load_ubyte %2, %6, off sc0\n\tglobal_load_ubyte %3, %7, off sc0\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(raw[2]), "=&v"(raw[3])
+                                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+                }
+#ifdef VK_GZ_STAMPS
+                if (any_far) qd += 1000;   // (diagnostics: per "round" / 1000 = batches with a source in memory per slab)
+#endif
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t e = s0 + 64u * (w0 + u) + lane;   // relative to `base`
-                        const uint32_t d = (tk[u] >> 9) & 0xFFFFu;
-                        uint32_t i = e - ts[u];
-                        const bool act = e < r1 && (tk[u] >> 31) != 0u;
-                        if (act && i >= d) i = d == 1u ? 0u : i % d;
-                        src[u] = static_cast<long long>(base + ts[u]) - static_cast<long long>(d) + i;
-                        if (!act) src[u] = 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) raw[u] = load_raw(src[u] < 0 ? 0 : src[u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t e = s0 + 64u * (w0 + u) + lane;
-                        uint32_t v = raw[u];
-                        if (SYM && src[u] < 0) v = 0x8000u | static_cast<uint32_t>(src[u] + 32768);  // the unknown window
-                        if ((tk[u] >> 31) == 0u) v = tk[u] & 0xFFu;
-                        if (e < r1) store_elem(base + e, v);
+                for (uint32_t k = 0; k < kGzBatch; ++k) {
+                    if (k < nslab) {
+                        const uint32_t s0 = b0 + 64u * k;
+                        const uint32_t e = s0 + static_cast<uint32_t>(lane);
+                        const bool act = e < total;
+                        uint32_t v = ref[k] == kFar ? raw[k] : val[k];
+                        const bool pend = ref[k] >= 0;
+                        const bool earlier = pend && ref[k] < static_cast<int32_t>(s0);   // written by a slab of this batch before this one
+                        const bool inslab = pend && !earlier;
+                        if (earlier) v = hist[(base_lo + static_cast<uint32_t>(ref[k])) & (kGzHist - 1u)];
+                        if (__any(inslab)) {
+                            // chains inside the slab, in registers: P = the lane this lane's element comes from (itself when it is
+                            // final); P = P[P] until nothing moves (a chain of n links: log2 n + 1 passes), then one fetch
+                            uint32_t P = inslab ? static_cast<uint32_t>(ref[k]) - s0 : static_cast<uint32_t>(lane);
+                            for (;;) {
+                                const uint32_t PP = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(P << 2), static_cast<int>(P)));
+                                const bool moved = PP != P;
+                                P = PP;
+                                if (!__any(moved)) break;
+                            }
+                            const uint32_t vv = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(P << 2), static_cast<int>(v)));
+                            if (inslab) v = vv;
+                        }
+                        if (act) hist[(base_lo + e) & (kGzHist - 1u)] = static_cast<uint16_t>(v);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the next slab reads hist; the hardware keeps a wave's LDS operations in order)
+                        if (act) store_elem(base + e, v);
+                        ++rounds;
                     }
                 }
             }
@@ -713,14 +778,8 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
             __builtin_amdgcn_sched_barrier(0);
             qc += q3 - q2;
 #endif
-            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the stores of this round have reached L2
-            GZ_T(q1);
-            GZ_ADD(qd, q3, q1);
-            ++rounds;
-            done = upto;
-            r0 = r1;
-            frontier = static_cast<long long>(base + r1);
         }
+        lds_fence();   // hist is read by the next group's slabs
         base += total;
     }
 #ifdef VK_GZ_STAMPS
@@ -741,7 +800,7 @@ __device__ __attribute__((noinline)) GzRes gz_resolve(GzLdsP L, void* out_, uint
 // (w = 32768 + position relative to the chunk's first byte); vk_gzwin_kernel / vk_gzfinal_kernel
 // replace them once the windows are known.
 template <bool SYM>
-__device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
+__device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
                         uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
                         uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
                         uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc, uint2* memrec) {
@@ -763,6 +822,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
     // a chunk that begins inside a member lies in the unknown window (at most 32768 before the chunk)
     bool window_open = SYM && !at_header;
     uint64_t member_text0 = 0;
+    uint64_t hist_from = 0;      // the output from here on went through the resolver's history (a stored block does not)
 
     auto load_elem = [&](long long p) -> uint32_t {  // element at output position p (p < 0: the unknown window)
         if (SYM) {
@@ -783,8 +843,8 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
         GZ_T(r0);
         n_tok += nring;
 #endif
-        const GzRes r = gz_resolve<SYM>((GzLdsP)(&L), SYM ? static_cast<void*>(out16) : static_cast<void*>(out8),
-                                        cap, opos, nring, window_open ? 1u : 0u, member_text0);
+        const GzRes r = gz_resolve_slabs<SYM>((GzLdsP)(&L), (GzHistP)hist, SYM ? static_cast<void*>(out16) : static_cast<void*>(out8),
+                                              cap, opos, nring, window_open ? 1u : 0u, member_text0, hist_from);
         opos = gz_uni64(r.opos);
         st |= gz_uni(r.st);
         nring = 0;
@@ -865,6 +925,7 @@ __device__ void gz_wave(GzLds& L, const uint8_t* __restrict__ in, uint64_t nbyte
                 for (uint32_t i = lane; i < len; i += 64) store_elem(opos + i, in[b + 4 + i]);
                 __builtin_amdgcn_s_waitcnt(0x0070);
                 opos += len;
+                hist_from = opos;
                 pos = (b + 4 + len) * 8;
                 block_done = true;
             } else if (type == 3) {
@@ -961,11 +1022,12 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
                                                          uint32_t* __restrict__ status, uint32_t* __restrict__ members,
                                                          uint32_t* __restrict__ crc, uint2* __restrict__ memrec) {
     __shared__ GzLds L;
+    __shared__ uint16_t hist[kGzHist];
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
     uint64_t n = 0, endbit = 0;
     uint32_t st = 0, next = 0, isum = 0, nm = 0, cr = 0;
-    gz_wave<false>(L, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
+    gz_wave<false>(L, hist, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
                    nullptr, 0, 0, n, st, next, endbit, isum, nm, cr, memrec + static_cast<size_t>(job) * kGzMemRec);
     if ((threadIdx.x & 63) == 0) {
         out_len[job] = n;
@@ -991,7 +1053,11 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
 // room, sizes that do not add up) sends the file through vk_inflate_kernel instead.
 constexpr uint32_t kGzChunkMin = 1u << 17;                            // compressed bytes per chunk: this, or twice this
 constexpr uint32_t kGzBigFile = 1u << 19;                             // files at least this large are cut into chunks
-constexpr uint32_t kGzChunkWaves = 28;                                // wavefronts of vk_gzchunk_kernel a CU holds (7 per SIMD)
+#ifndef VK_GZ_CHUNK_OCC
+#define VK_GZ_CHUNK_OCC 6     // wavefronts of vk_gzchunk_kernel per SIMD the register budget is set for
+#endif
+constexpr uint32_t kGzChunkLds = static_cast<uint32_t>(sizeof(GzLds)) + 2u * kGzHist;
+constexpr uint32_t kGzChunkWaves = (160u * 1024u / kGzChunkLds) < 4u * VK_GZ_CHUNK_OCC ? (160u * 1024u / kGzChunkLds) : 4u * VK_GZ_CHUNK_OCC;   // wavefronts of vk_gzchunk_kernel a CU holds (LDS, registers)
 
 __global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
                                                         uint32_t nchunks_total, uint64_t* __restrict__ starts) {
@@ -1127,7 +1193,7 @@ __global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restr
     if (lane == 0) starts[c] = found;
 }
 
-__global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
+__global__ __launch_bounds__(64, VK_GZ_CHUNK_OCC) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
                                                          const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
                                                          const uint64_t* __restrict__ starts,
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
@@ -1135,6 +1201,7 @@ __global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __rest
                                                          uint32_t* __restrict__ members, uint32_t* __restrict__ crc,
                                                          uint2* __restrict__ memrec) {
     __shared__ GzLds L;
+    __shared__ uint16_t hist[kGzHist];
     const uint32_t c = blockIdx.x;
     if (c >= nchunks_total) return;
     const GzChunk ch = chunks[c];
@@ -1145,7 +1212,7 @@ __global__ __launch_bounds__(64, 7) void vk_gzchunk_kernel(const uint8_t* __rest
     if (s0 == kGzNone) {
         st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
     } else {
-        gz_wave<true>(L, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
+        gz_wave<true>(L, hist, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
                       starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr, memrec + static_cast<size_t>(c) * kGzMemRec);
     }
     if ((threadIdx.x & 63) == 0) {

@@ -299,59 +299,44 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
     const uint32_t ncode = (static_cast<uint32_t>(w >> 10) & 15u) + 4;
     pos += 14;
     if (nlit > 286 || ndist > 30) return false;
-    // code-length code: ncode lengths of 3 bits in a fixed order
-    uint32_t pl[19];
-#pragma unroll
-    for (int i = 0; i < 19; ++i) pl[i] = 0;
+    // code-length code: ncode lengths of 3 bits in a fixed order.  Lane s < 19 takes the length of symbol s (its place in
+    // that order: 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15); counts by ballot, the canonical code
+    // of a symbol = first code of its length + the symbols of that length below it; the 7-bit lookup table is filled two
+    // entries per lane, every lane going through the 19 symbols.  (Until round 5 every lane kept all 19 lengths in
+    // registers behind select chains and lane 0 filled the table alone: ~1,500 instructions per header, and
+    // vk_gzfind_kernel parses 47 false ones per chunk -- 70 % of its time.)
     w = W.peek(in, nbytes, pos, lane);
-    for (uint32_t i = 0; i < ncode; ++i) {
-        const uint32_t v = static_cast<uint32_t>(w >> (3 * i)) & 7u;
-#pragma unroll
-        for (int k = 0; k < 19; ++k) pl[k] = (gz_pre_order(i) == static_cast<uint32_t>(k)) ? v : pl[k];
-    }
+    const uint32_t sym_l = static_cast<uint32_t>(lane);
+    const uint32_t place = sym_l == 0u ? 3u : (sym_l < 8u ? 19u - 2u * sym_l : (sym_l < 16u ? 2u * sym_l - 12u : sym_l - 16u));
+    const uint32_t mylen = (sym_l < 19u && place < ncode) ? static_cast<uint32_t>(w >> (3u * place)) & 7u : 0u;
     pos += 3 * ncode;
-    // its 7-bit lookup table (small: every lane computes the codes, lane 0 stores)
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, first[8];
-#pragma unroll
-    for (int k = 0; k < 19; ++k) {
-#pragma unroll
-        for (int l = 1; l < 8; ++l) cnt[l] += pl[k] == static_cast<uint32_t>(l) ? 1u : 0u;
-    }
     int left = 1;
-    uint32_t code = 0;
-    first[0] = 0;
+    uint32_t code = 0, prev_cnt = 0, mycode = 0;
     bool ok = true;
 #pragma unroll
-    for (int l = 1; l < 8; ++l) {
-        left = left * 2 - static_cast<int>(cnt[l]);
+    for (uint32_t l = 1; l < 8; ++l) {
+        const uint32_t m = static_cast<uint32_t>(__ballot(mylen == l));   // symbols 0..18: bits 0..18
+        const uint32_t c = static_cast<uint32_t>(__builtin_popcount(m));
+        left = left * 2 - static_cast<int>(c);
         if (left < 0) ok = false;
-        code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;
-        first[l] = code;
+        code = (code + prev_cnt) << 1;       // first code of length l
+        prev_cnt = c;
+        if (mylen == l) mycode = code + static_cast<uint32_t>(__builtin_popcount(m & ((1u << sym_l) - 1u)));
     }
     if (!ok || left > 0) return false;
-    for (uint32_t i = lane; i < 128; i += 64) L.pre[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        uint32_t next[8];
-#pragma unroll
-        for (int l = 0; l < 8; ++l) next[l] = first[l];
-        for (uint32_t s = 0; s < 19; ++s) {
-            uint32_t l = 0;
-#pragma unroll
-            for (int k = 0; k < 19; ++k) l = s == static_cast<uint32_t>(k) ? pl[k] : l;
-            if (l == 0) continue;
-            uint32_t c = 0;
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                if (l == static_cast<uint32_t>(k)) {
-                    c = next[k];
-                    next[k] = c + 1;
-                }
-            }
-            for (uint32_t idx = gz_rev(c, l); idx < 128; idx += 1u << l) L.pre[idx] = static_cast<uint8_t>(s | (l << 5));
-        }
+    const uint32_t myrev = mylen ? gz_rev(mycode, mylen) : 0u;
+    uint32_t e0 = 0, e1 = 0;   // entries `lane` and `lane + 64` of the table: sym | len << 5
+#pragma unroll 1
+    for (int sidx = 0; sidx < 19; ++sidx) {
+        const uint32_t ls = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mylen), sidx));
+        if (ls == 0u) continue;   // (wave-uniform)
+        const uint32_t rs = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myrev), sidx));
+        const uint32_t msk = (1u << ls) - 1u, ent = static_cast<uint32_t>(sidx) | (ls << 5);
+        if ((sym_l & msk) == rs) e0 = ent;
+        if (((sym_l + 64u) & msk) == rs) e1 = ent;
     }
+    L.pre[lane] = static_cast<uint8_t>(e0);
+    L.pre[lane + 64] = static_cast<uint8_t>(e1);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the nlit + ndist code lengths, run-length coded with the code-length code
@@ -394,6 +379,9 @@ __device__ bool gz_dynamic_header(GzLds& L, const uint8_t* __restrict__ in, uint
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (an incomplete literal/length code is no header either -- gz_build<true> says the same, a table build later: most of what
+    // vk_gzfind_kernel parses to the end fails here)
+    if (kraft_lit != 32768u) return false;
     return L.lens[256] != 0;  // a block without an end-of-block code is not valid
 }
 

@@ -40,8 +40,8 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     batch_bytes: None = DEFAULT_BATCH_BYTES (DEFAULT_GZ_BATCH_BYTES when every file is gzip).
     timings: optional dict that receives where this thread's wall time went (seconds): waiting for the
     staging thread (`stage_wait_s`), the copy to the device and the inflate (`upload_s`, of which
-    `inflate_s`), kernels + copies back (`kernels_s`), handing images to the PNG pool (`png_submit_s`)
-    and waiting for the last PNGs (`png_tail_s`); `batches`."""
+    `inflate_s`), kernels + copies back (`kernels_s`) and waiting for the last hand-overs and PNGs (`png_tail_s`);
+    `png_submit_s` = handing images to the PNG pool, on a thread of its own since round 5 (not this thread's time); `batches`."""
     from .engine import ImageEngine
     files = [Path(f) for f in files]
     labels = labels or {}
@@ -86,6 +86,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     # The host half of a batch (file reads into a pinned buffer) runs one batch ahead on its own
     # thread, into the other of two staging buffers, while this thread copies and processes.
     stager = ThreadPoolExecutor(1)
+    finisher, handed = ThreadPoolExecutor(1), []
     staged = stager.submit(eng.stage_files, batches[0][0], pool, 0) if batches else None
     for bi, (batch, nbytes) in enumerate(batches):
         t0 = time.perf_counter()
@@ -103,26 +104,36 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         nz = (hist != 0).any(dim=1).cpu().numpy()
         t2 = time.perf_counter()
         tm["kernels_s"] += t2 - t1
-        for j, f in enumerate(batch):
-            key = str(f.name.removesuffix("".join(f.suffixes)))
-            s = stats.setdefault(key, OrderedDict())
-            if st[j] or not nz[j]:
-                eprint("K-MER COUNTING FAIL, SKIPPING FILE:", f)
-                s["failed_step"] = "image"
-                continue
-            s[str(k) + "mer_counting_time"] = (t2 - t0) / len(batch)
-            d, name = target(f)
-            d.mkdir(parents=True, exist_ok=True)
-            sample = key.split("@")[0]
-            sd = base_sd.get(sample, 0)
-            pending.append((key, time.perf_counter(),
-                            pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
-                                        QUAL_THRESH, mapping_code)))
-        tm["png_submit_s"] += time.perf_counter() - t2
+
+        def hand_over(batch=batch, st=st, imgs=imgs, nz=nz, per_file=(t2 - t0) / len(batch)):
+            # stats rows and PNG jobs of one batch: on a thread of its own (batches in order), beside the next batch's
+            # upload and inflate, in whose C calls this thread's interpreter lock is free (9 % of a .fq.gz pass before)
+            th = time.perf_counter()
+            for j, f in enumerate(batch):
+                key = str(f.name.removesuffix("".join(f.suffixes)))
+                s = stats.setdefault(key, OrderedDict())
+                if st[j] or not nz[j]:
+                    eprint("K-MER COUNTING FAIL, SKIPPING FILE:", f)
+                    s["failed_step"] = "image"
+                    continue
+                s[str(k) + "mer_counting_time"] = per_file
+                d, name = target(f)
+                d.mkdir(parents=True, exist_ok=True)
+                sample = key.split("@")[0]
+                sd = base_sd.get(sample, 0)
+                pending.append((key, time.perf_counter(),
+                                pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
+                                            QUAL_THRESH, mapping_code)))
+            tm["png_submit_s"] += time.perf_counter() - th   # (this thread's time: off the main thread's path)
+
+        handed.append(finisher.submit(hand_over))
         if verbose:
             eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
     stager.shutdown()
     tt = time.perf_counter()
+    for h in handed:
+        h.result()   # (an exception of a batch's hand-over surfaces here)
+    finisher.shutdown()
     for key, t, fut in pending:
         fut.result()
         stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t

@@ -579,7 +579,7 @@ struct GzRes {
 // SYM = false: text bytes; SYM = true: u16 elements, positions before the chunk stand for the unknown window.
 typedef __attribute__((address_space(3))) uint16_t* GzHistP;
 #ifndef VK_GZ_HIST
-#define VK_GZ_HIST 512
+#define VK_GZ_HIST 512   // (512: the block of loads for sources in memory is written for a batch of four slabs; 1024 / 8 measured slower, profiles/ab/r05_gz_resolver.txt)
 #endif
 constexpr uint32_t kGzHist = VK_GZ_HIST;   // elements of history in LDS
 constexpr uint32_t kGzBatch = kGzHist / 128;   // slabs resolved together: half of hist

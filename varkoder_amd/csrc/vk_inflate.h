@@ -688,7 +688,15 @@ __device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hi
                         const uint32_t d = (tk >> 9) & 0xFFFFu;
                         uint32_t i = e - ts;
                         if (__any(mt && i >= d)) {   // a match that overlaps its own output: the source taken modulo the distance
-                            if (mt && i >= d) i = d == 1u ? 0u : i % d;
+                            // (i < 258 + 64, d <= 32768: a reciprocal and one correction step -- hipcc's 32-bit `%` is ~35 instructions,
+                            // and runs of one byte or one short unit are in most slabs of a FASTQ's quality lines)
+                            if (mt && i >= d) {
+                                const uint32_t q = static_cast<uint32_t>(static_cast<float>(i) * __builtin_amdgcn_rcpf(static_cast<float>(d)));
+                                int32_t r = static_cast<int32_t>(i) - static_cast<int32_t>(__umul24(q, d));
+                                if (r < 0) r += static_cast<int32_t>(d);
+                                else if (r >= static_cast<int32_t>(d)) r -= static_cast<int32_t>(d);
+                                i = static_cast<uint32_t>(r);
+                            }
                         }
                         const int32_t src = static_cast<int32_t>(ts + i) - static_cast<int32_t>(d);   // relative to base, below ts
                         uint32_t v = tk & 0xFFu;

@@ -237,12 +237,11 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
             auto round = [&](uint32_t n) {  // xb[0 .. n) are real, lanes beyond idle along on newlines
                 uint32_t C[64], bad[64];
                 for (uint32_t lane = 0; lane < 64; ++lane) {
-                    Granule q = {{0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au}};
+                    Granule q = {{0x0A0A0A0Au, 0x0A0A0A0Au | vkl::kGranuleEnd, 0x0A0A0A0Au, 0x0A0A0A0Au}};
                     if (lane < n) q = xb[lane];
-                    uint32_t IV, SEQ;
-                    vkl::classify_granule(q.a[0] & ~vkl::kGranuleStartTag, q.a[1], q.a[2], q.a[3],
-                                          (q.a[0] & vkl::kGranuleStartTag) != 0u, C[lane], IV, SEQ);
-                    bad[lane] = (IV | ~SEQ) & 0x55555555u;
+                    uint32_t SEQ;
+                    vkl::classify_granule_note(q.a[0], q.a[1], q.a[2], q.a[3], C[lane], bad[lane], SEQ);
+                    if (stats) stats[5] += vkl::popc(SEQ & 0x55555555u);   // sequence bytes the notes name
                 }
                 for (uint32_t lane = 0; lane < 64; ++lane) {
                     const uint32_t badh = lane ? bad[lane - 1] : ctx_bad, ch = lane ? C[lane - 1] : ctx_c;
@@ -279,7 +278,8 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
                         lphs[lane] = (pph + excl) & 3u;
                         excl += c;
-                        plainl[lane] = vkl::seq_span(mlo, mhi, c, lphs[lane], sp[lane], ep[lane]);
+                        uint32_t s_raw;
+                        plainl[lane] = vkl::seq_span_note(mlo, mhi, c, lphs[lane], sp[lane], ep[lane], s_raw);
                         na += plainl[lane] ? 0u : 1u;
                     }
                     total = excl;
@@ -290,9 +290,8 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                             if (plainl[lane]) continue;
                             const bool before = lane == 0 ? aside63 : !plainl[lane - 1];
                             alist.push_back(((it * 64u + (uint32_t)lane) << 3) | (before ? 4u : 0u) | lphs[lane]);
-                            memset(piece + 64 * lane, '\n', 16);
                             sp[lane] = 0;
-                            ep[lane] = 15;
+                            ep[lane] = 0;
                             if (stats) stats[4]++;
                         }
                         aside63 = !plainl[63];
@@ -308,7 +307,12 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         for (uint32_t g = gs; g < gs + n; ++g) {
                             Granule q;
                             memcpy(q.a, piece + 64 * lane + 16 * g, 16);
-                            if (g == gs && vkl::span_starts_inside(sl)) q.a[0] |= vkl::kGranuleStartTag;
+                            // the notes of the edge granules (vk_count.h: set on the copy in the exchange buffer)
+                            if (g == gs && vkl::span_starts_inside(sl)) q.a[0] |= vkl::note_spread(sl & 15u);
+                            if (el < 64u && g == vkl::span_last(el)) {
+                                q.a[0] |= vkl::note_spread(el & 15u);
+                                q.a[1] |= vkl::kGranuleEnd;
+                            }
                             xb[npend++] = q;
                             if (npend == 64) {
                                 round(64);

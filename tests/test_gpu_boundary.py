@@ -381,8 +381,8 @@ def test_c_abi_from_plain_c(tmp_path):
 def test_cli_image_at_world_two_equals_single_rank(tmp_path):
     """The product entry under a launcher: `torchrun --nproc-per-node 2 -m varkoder_amd image ...` (both
     ranks on cuda:0 here, started by torch.distributed.run BEFORE anything touches the GPU) writes the
-    same PNG files and the same merged stats.csv rows as a single-rank run -- samples are sharded
-    round-robin, rank 0 merges the per-sample stats (reference: commands/image.py:1281-1284, 1144-1170)."""
+    same PNG files and the same merged stats.csv rows as a single-rank run -- files are dealt by size
+    (shard.shard_by_size), rank 0 merges the per-sample stats (reference: commands/image.py:1281-1284, 1144-1170)."""
     import os
     import socket
     import subprocess
@@ -425,3 +425,101 @@ def test_cli_image_at_world_two_equals_single_rank(tmp_path):
     assert s2.set_index("sample").loc["broken_Z", "failed_step"] == "image"
     timed = [c for c in s2.columns if c.endswith("_time")]
     assert timed and (s2.set_index("sample").drop("broken_Z")[timed] > 0).all().all()
+
+
+def _torchrun_image(root, env, port, args, timeout=900):
+    import subprocess
+    import sys
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "varkoder_amd"] + args,
+                          capture_output=True, text=True, timeout=timeout, cwd=root,
+                          env=dict(env, VARKODER_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _launcher_env(root):
+    import os
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "LOCAL_WORLD_SIZE")}
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
+@pytest.mark.gpu
+def test_cli_image_at_world_two_sums_a_samples_ladder_over_the_ranks(tmp_path):
+    """Ladder-shaped input -- four rungs per sample, as split_fastq leaves them (commands/image.py:682-708): dealt by size,
+    a sample's rungs land on BOTH ranks.  The PNG bytes equal a single-rank run's, and a sample's `<k>mer_counting_time`
+    / `k<k>_img_time` in stats.csv is the sum over ALL its files on all ranks (the reference accumulates over a sample's
+    files, commands/image.py:1078) -- until round 6 the last rank's share overwrote the others'."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    split = tmp_path / "int" / "split_fastqs"
+    split.mkdir(parents=True)
+    rungs = [150, 300, 750, 1500]   # Kbp names; reads per file in proportion
+    for i in range(3):
+        for kbp in rungs:
+            _write_fastq(split / f"tax{i}_S@{kbp:08d}K.fq", 200 + 10 * i + kbp % 7, kbp * 1000 // 150)
+    env = _launcher_env(root)
+    common = ["image", str(tmp_path / "int"), "-k", "7", "-p", "cgr", "-n", "2"]
+    one = subprocess.run([sys.executable, "-m", "varkoder_amd"] + common +
+                         ["-o", str(tmp_path / "img1"), "-f", str(tmp_path / "stats1.csv")],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = _torchrun_image(root, dict(env, VARKODER_AMD_PER_FILE_STATS=str(tmp_path / "perfile")), _free_port(),
+                          common + ["-o", str(tmp_path / "img2"), "-f", str(tmp_path / "stats2.csv")])
+    assert two.returncode == 0, two.stderr[-3000:]
+    a = sorted(p.name for p in (tmp_path / "img1").rglob("*.png"))
+    b = sorted(p.name for p in (tmp_path / "img2").rglob("*.png"))
+    assert a == b and len(a) == 12
+    for name in a:
+        assert next((tmp_path / "img1").rglob(name)).read_bytes() == next((tmp_path / "img2").rglob(name)).read_bytes()
+    parts = [json.load(open(str(tmp_path / "perfile") + f".rank{r}.json")) for r in range(2)]
+    assert all(parts) and not set(parts[0]) & set(parts[1]) and len(parts[0]) + len(parts[1]) == 12
+    # the rungs of at least one sample were split over the ranks (LPT over four sizes x three samples on two ranks)
+    assert any({k.split("@")[0] for k in parts[0]} & {k.split("@")[0] for k in parts[1]})
+    s2 = pd.read_csv(tmp_path / "stats2.csv").set_index("sample")
+    for col in ("7mer_counting_time", "k7_img_time"):
+        for sample in (f"tax{i}_S" for i in range(3)):
+            want = sum(v[col] for part in parts for k, v in part.items() if k.split("@")[0] == sample)
+            assert abs(float(s2.loc[sample, col]) - want) <= 1e-9 * max(1.0, want), (sample, col)
+
+
+@pytest.mark.gpu
+def test_cli_image_with_a_failing_rank_ends_at_once(tmp_path):
+    """One rank of a two-rank `image` job raises before its share (VARKODER_AMD_FAULT: the stand-in for a device out of
+    memory or a full disk): the job ends within seconds with a non-zero exit code -- the failing rank still goes to the
+    gather and the barrier -- instead of hanging its peer in gather_object until the gloo timeout (30 minutes); the
+    other rank's images and stats rows are there."""
+    import os
+    import time
+
+    import pandas as pd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    split = tmp_path / "int" / "split_fastqs"
+    split.mkdir(parents=True)
+    for i in range(4):
+        _write_fastq(split / f"tax{i}_S@{150 * (1 + i):08d}K.fq", 300 + i, 1000 * (1 + i))
+    env = _launcher_env(root)
+    t0 = time.time()
+    two = _torchrun_image(root, dict(env, VARKODER_AMD_FAULT="rank1"), _free_port(),
+                          ["image", str(tmp_path / "int"), "-k", "7", "-p", "cgr", "-n", "2", "-o", str(tmp_path / "img"),
+                           "-f", str(tmp_path / "stats.csv")], timeout=600)
+    took = time.time() - t0
+    assert two.returncode != 0
+    assert "injected fault on rank 1" in two.stderr
+    assert took < 240, took                        # (start-up of two ranks + one rank's share; the gloo timeout is 1800 s)
+    pngs = sorted(p.name for p in (tmp_path / "img").rglob("*.png"))
+    assert 1 <= len(pngs) < 4                      # rank 0's share was made
+    st = pd.read_csv(tmp_path / "stats.csv")
+    assert 1 <= len(st) < 4

@@ -57,7 +57,7 @@ def emul():
         pad[:buf.size] = buf
         hist = np.zeros(4 ** k, dtype=np.uint32)
         st = C.c_uint32(0)
-        stats = (C.c_uint64 * 5)()
+        stats = (C.c_uint64 * 6)()
         L.emul_count_dense.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         assert L.emul_count_dense(pad.ctypes.data, buf.size, k, parts, hist.ctypes.data, C.byref(st), stats) == 0
         return hist, st.value, tuple(stats)
@@ -148,7 +148,7 @@ def test_dense_stage_equals_oracle_on_synthetic_and_takes_the_fast_path(emul, di
     fq = synth.sample_fastq(21, 40000, 150, dist=dist)   # 12.8 MB: ~190 pieces per wave at parts = 1
     for k, parts in ((5, 1), (7, 1), (7, 3), (6, 7)):
         want = oracle.count_fastq(fq, k)[0]
-        got, status, (fast, pieces, rounds, granules, explicit) = emul.dense(fq, k, parts)
+        got, status, (fast, pieces, rounds, granules, explicit, _noted) = emul.dense(fq, k, parts)
         assert status == 0 and explicit == 0
         assert np.array_equal(got, want), (k, parts)
         # every piece but the first and last of a range goes through the line pass, and the rounds are full
@@ -166,7 +166,7 @@ def test_dense_stage_keeps_fastp_shaped_reads_on_the_fast_path(emul):
     fq = synth.sample_fastq(33, 30000, 150, dist=2)
     for k, parts in ((7, 1), (5, 2), (6, 5)):
         want = oracle.count_fastq(fq, k)[0]
-        got, status, (fast, pieces, rounds, granules, explicit) = emul.dense(fq, k, parts)
+        got, status, (fast, pieces, rounds, granules, explicit, _noted) = emul.dense(fq, k, parts)
         assert status == 0
         assert np.array_equal(got, want), (k, parts)
         assert fast >= pieces - 2 * 16 * parts, (fast, pieces)

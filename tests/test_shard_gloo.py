@@ -125,6 +125,110 @@ def test_single_process_helpers_are_identity():
     assert shard.world_info()[1] >= 1
 
 
+def test_merge_stats_adds_the_ranks_shares_of_a_sample():
+    """Files are dealt by size, so one sample's ladder rungs land on several ranks: a timing is the SUM of the
+    ranks' shares (commands/image.py:1078 accumulates over a sample's files), a failed step stays, the rest is
+    taken as it comes."""
+    from collections import OrderedDict
+    from varkoder_amd import shard
+    a = {"s1": OrderedDict([("7mer_counting_time", 1.5), ("k7_img_time", 0.25), ("base_frequencies_sd", 0.1)]),
+         "s2": OrderedDict([("7mer_counting_time", 1.0), ("failed_step", "image")])}
+    b = {"s1": OrderedDict([("7mer_counting_time", 2.0), ("k7_img_time", 0.5), ("base_frequencies_sd", 0.1)]),
+         "s2": OrderedDict([("7mer_counting_time", 4.0), ("k7_img_time", 1.0)]),
+         "s3": OrderedDict([("failed_step", "split")])}
+    m = shard.merge_stats([a, b, None])
+    assert list(m) == ["s1", "s2", "s3"]
+    assert m["s1"] == {"7mer_counting_time": 3.5, "k7_img_time": 0.75, "base_frequencies_sd": 0.1}
+    assert m["s2"] == {"7mer_counting_time": 5.0, "failed_step": "image", "k7_img_time": 1.0}
+    assert m["s3"] == {"failed_step": "split"}
+    assert shard.gather_stats(a, error="boom", with_errors=True) == (shard.merge_stats([a]), ["boom"])
+
+
+def _failing_job_worker(rank, world, port, tmp, out):
+    """One rank of `varkoder_amd image`'s closing half (cli.finish_image_job); rank 1's share "raised"."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import time
+    from collections import OrderedDict
+    from pathlib import Path
+    import torch.distributed as dist
+    from varkoder_amd import cli
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(stats_file=os.path.join(tmp, "stats.csv"), label_table=True)
+    stats = {"s1": OrderedDict([("7mer_counting_time", 1.0 + rank), ("k7_img_time", 0.5)])}
+    error = OSError("cannot write into the output folder") if rank == 1 else None
+    if rank == 1:
+        stats = {}
+    t0 = time.time()
+    try:
+        cli.finish_image_job(args, Path(tmp), rank, world, stats, error, ["s1"], {}, {})
+        out.put((rank, "ok", time.time() - t0))
+    except Exception as e:   # noqa: BLE001
+        out.put((rank, repr(e), time.time() - t0))
+        sys.exit(3)
+
+
+def test_a_failing_rank_ends_the_image_job_at_once_on_every_rank(tmp_path):
+    """A rank whose share raised still goes to the gather and the barrier (its error rides with its stats): nobody waits
+    for the backend's timeout, rank 0 still writes the stats of what finished, every rank exits non-zero."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_job_worker, args=(r, world, port, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 3
+    assert "cannot write" in got[0][1] and "cannot write" in got[1][1]
+    assert max(t for _, _, t in got) < 60
+    import pandas as pd
+    df = pd.read_csv(tmp_path / "stats.csv")
+    assert list(df["sample"]) == ["s1"] and float(df["7mer_counting_time"][0]) == 1.0
+    assert not (tmp_path / "labels.csv").exists()
+
+
+def _weights_worker(rank, world, port, tmp, out):
+    sys.path.insert(0, ROOT)
+    from pathlib import Path
+    import torch.distributed as dist
+    from varkoder_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    files = sorted(Path(tmp).glob("*.fq"))
+    if rank == 1:   # this rank's view of the sizes differs (a file still being written, an attribute cache)
+        real = shard.file_weights
+        shard.file_weights = lambda fs: list(reversed(real(fs)))
+    own = shard.file_weights(files)
+    w = shard.agreed_weights(files)
+    out.put((rank, own, w, shard.shard_by_size(w, rank, world)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_see_different_sizes_still_partition_the_files(tmp_path):
+    """shard_by_size is only a partition when every rank feeds it the same weights: rank 0's view is broadcast."""
+    for i, n in enumerate([1000, 900, 800, 700, 50]):
+        (tmp_path / f"f{i}.fq").write_bytes(b"a" * n)
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_weights_worker, args=(r, world, port, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, own0, w0, mine0), (_, own1, w1, mine1) = got
+    assert own1 != own0 and w0 == w1 == own0      # rank 0's view, on both
+    assert sorted(mine0 + mine1) == list(range(5))   # every file exactly once
+
+
 def _giant_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import torch

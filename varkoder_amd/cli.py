@@ -11,6 +11,7 @@ process_stats does (commands/image.py:1144-1185).  With torchrun, ranks shard th
 """
 import argparse
 import math
+import os
 import shutil
 import sys
 from collections import OrderedDict, defaultdict
@@ -127,7 +128,7 @@ def run_query(args):
     from .convert import get_metadata_from_img_filename
     from .engine import ImageEngine
     from .image import write_png
-    from .shard import file_weights, shard_by_size, world_info
+    from .shard import agreed_weights, shard_by_size, world_info
     from .subsample import ladder_counts, split_name
     rank, world, device = world_info()
     outdir = Path(args.outdir)
@@ -150,10 +151,11 @@ def run_query(args):
     # closing barrier; the exception is raised after the process group is gone.
     state = {"eng": None}
     model = vocab = None
+    weights = agreed_weights(inputs)   # (a collective: outside the try block, every rank is still here)
 
     def rank_work():
         nonlocal model, vocab
-        mine = shard_by_size(file_weights(inputs), rank, world)
+        mine = shard_by_size(weights, rank, world)
         model, vocab = Q.load_model(args.model), Q.read_vocab(args.vocab)
         records, images, order = [], None, []   # order: index of each record's input in `inputs`
         eng = None
@@ -273,9 +275,8 @@ def parse_size(text):
 
 def run_image_from_clean(args, outdir, rank, world, local_rank):
     import numpy as np
-    import pandas as pd
     from .pipeline import clean_to_images
-    from .shard import gather_stats, io_threads_per_rank
+    from .shard import io_threads_per_rank
     src = Path(args.input)
     if (src / "clean_reads").is_dir():
         src = src / "clean_reads"
@@ -291,33 +292,79 @@ def run_image_from_clean(args, outdir, rank, world, local_rank):
     from .image import base_sd_table
     base_sd = base_sd_table(src, samples)                                     # image.py:1094-1097
     eprint("Subsampling, counting kmers and creating images for", len(files), "samples")
-    per_sample = clean_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping,
-                                 min_bp=parse_size(args.min_bp), max_bp=max_bp, seeds=seeds, labels=labels,
-                                 base_sd=base_sd,
-                                 device=local_rank, rank=rank, world=world, io_threads=io_threads_per_rank(args.n_threads),
-                                 verbose=args.verbose)
-    for s, v in per_sample.items():
-        v["base_frequencies_sd"] = base_sd.get(s, 0)
-    merged = gather_stats(per_sample)
+    per_sample, error = OrderedDict(), None
+    from .shard import agreed_weights
+    weights = agreed_weights(files)   # (a collective: before the try block, while every rank is still here)
+    try:   # (a rank whose share fails still reaches the gather below: see finish_image_job)
+        failpoint(rank)
+        per_sample = clean_to_images(files, outdir, weights=weights, k=args.kmer_size, mapping_code=args.kmer_mapping,
+                                     min_bp=parse_size(args.min_bp), max_bp=max_bp, seeds=seeds, labels=labels,
+                                     base_sd=base_sd,
+                                     device=local_rank, rank=rank, world=world, io_threads=io_threads_per_rank(args.n_threads),
+                                     verbose=args.verbose)
+        for s, v in per_sample.items():
+            v["base_frequencies_sd"] = base_sd.get(s, 0)
+    except Exception as e:   # noqa: BLE001 -- reported by finish_image_job, once every rank is past its collectives
+        error = e
+    finish_image_job(args, outdir, rank, world, per_sample, error, samples, labels, base_sd)
+
+
+def failpoint(rank):
+    """Test hook: VARKODER_AMD_FAULT=rank<r> makes rank r's share of an `image` job raise before it starts (the tests of
+    the job's failure isolation need a rank that fails for a reason no input file carries: a device out of memory, a
+    full disk)."""
+    if os.environ.get("VARKODER_AMD_FAULT") == "rank%d" % rank:
+        raise RuntimeError("injected fault on rank %d (VARKODER_AMD_FAULT)" % rank)
+
+
+def finish_image_job(args, outdir, rank, world, per_sample, error, samples, labels, base_sd):
+    """The closing half of `image` on every rank: gather the ranks' per-sample stats (and errors) on rank 0, write
+    stats.csv / labels.csv there, meet at the barrier, leave the group -- and only then raise what went wrong.
+
+    The reference's pool loses ONE sample when a worker dies on it (commands/image.py:1070-1075, :1281-1284); a job of
+    ranks that share collectives loses every rank unless the failing one still shows up for them: an exception on one
+    rank (the device out of memory in a copy, a PNG that cannot be written) used to leave the others inside
+    gather_object until the gloo timeout.  Now the error travels with the gathered object, every rank reaches the
+    gather and the barrier, rank 0 still writes the stats of what did finish, and every rank exits non-zero."""
+    import pandas as pd
+    from .shard import gather_stats
+    text = None if error is None else "rank %d: %r" % (rank, error)
+    merged, errors = gather_stats(per_sample, error=text, with_errors=True)
+    failure = error
     if rank == 0:
-        rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
-        pd.DataFrame(rows).to_csv(args.stats_file, index=False)
-        if args.label_table:                                                  # image.py:1172-1185
-            lt = pd.DataFrame({"sample": samples,
-                               "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
-                               "possible_low_quality": [base_sd.get(s, 0) > QUAL_THRESH for s in samples]})
-            lt.to_csv(outdir / "labels.csv", index=False)
-        eprint("All images done, saved in", str(outdir))
+        try:
+            rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
+            pd.DataFrame(rows).to_csv(args.stats_file, index=False)
+            if args.label_table and not errors:                               # image.py:1172-1185
+                lt = pd.DataFrame({"sample": samples,
+                                   "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
+                                   "possible_low_quality": [base_sd.get(s, 0) > QUAL_THRESH for s in samples]})
+                lt.to_csv(outdir / "labels.csv", index=False)
+            if errors:
+                eprint("image failed on", "; ".join(errors))
+                if failure is None:
+                    failure = Exception("image failed on " + "; ".join(errors))
+            else:
+                eprint("All images done, saved in", str(outdir))
+        except Exception as e:   # noqa: BLE001
+            failure = failure or e
     if world > 1:
         import torch.distributed as dist
+        # every rank learns whether the job failed (a rank whose own share was fine must not report success)
+        flag = [failure is not None]
+        verdict = [None] * world
+        dist.all_gather_object(verdict, flag[0])
         dist.barrier()
         dist.destroy_process_group()
+        if failure is None and any(verdict):
+            failure = Exception("image failed on another rank")
+    if failure is not None:
+        raise failure
 
 
 def run_image(args):
-    import pandas as pd
     from .pipeline import fastqs_to_images
-    from .shard import gather_stats, io_threads_per_rank, world_info
+    from .shard import io_threads_per_rank, world_info
     if args.kmer_size not in range(KMER_MIN, KMER_MAX + 1):
         raise ValueError("kmer size must be between 5 and 9")               # image.py:1209-1210
     rank, world, local_rank = world_info()
@@ -358,33 +405,33 @@ def run_image(args):
     eprint("Counting kmers and creating images for", len(files), "files of", len(samples), "samples")
     if args.no_image:
         return
-    per_file = fastqs_to_images(files, outdir, k=args.kmer_size, mapping_code=args.kmer_mapping, labels=labels,
-                                base_sd=base_sd, overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
-                                world=world, io_threads=io_threads_per_rank(args.n_threads), verbose=args.verbose)
-    # fold the per-file stats into per-sample stats like run_clean2img does (image.py:1057-1125)
-    mine = defaultdict(OrderedDict)
-    ck, ik = f"{args.kmer_size}mer_counting_time", f"k{args.kmer_size}_img_time"
-    for key, st in per_file.items():
-        s = mine[key.split(SAMPLE_BP_SEP)[0]]
-        for name in (ck, ik):
-            s[name] = s.get(name, 0) + st.get(name, 0)
-        if "failed_step" in st:
-            s["failed_step"] = st["failed_step"]
-    for name, st in mine.items():
-        st["base_frequencies_sd"] = base_sd.get(name, 0)
-    merged = gather_stats(mine)
-    if rank == 0:
-        rows = [OrderedDict([("sample", s)] + list(v.items())) for s, v in merged.items()]
-        pd.DataFrame(rows).to_csv(args.stats_file, index=False)
-        if args.label_table:
-            lt = pd.DataFrame({"sample": samples,
-                               "labels": [LABELS_SEP.join(labels.get(s, [])) for s in samples],
-                               "possible_low_quality": [base_sd.get(s, 0) > QUAL_THRESH for s in samples]})
-            lt.to_csv(outdir / "labels.csv", index=False)
-        eprint("All images done, saved in", str(outdir))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    mine, error = defaultdict(OrderedDict), None
+    from .shard import agreed_weights
+    weights = agreed_weights(files)   # (a collective: before the try block, while every rank is still here)
+    try:   # (a rank whose share fails still reaches the gather: see finish_image_job)
+        failpoint(rank)
+        per_file = fastqs_to_images(files, outdir, weights=weights, k=args.kmer_size, mapping_code=args.kmer_mapping, labels=labels,
+                                    base_sd=base_sd, overwrite=True, subfolder_levels=levels, device=local_rank, rank=rank,
+                                    world=world, io_threads=io_threads_per_rank(args.n_threads), verbose=args.verbose)
+        # fold the per-file stats into per-sample stats like run_clean2img does (image.py:1057-1125); files are dealt by
+        # size, so other ranks may hold further files of the same sample: shard.merge_stats adds the ranks' shares up
+        ck, ik = f"{args.kmer_size}mer_counting_time", f"k{args.kmer_size}_img_time"
+        if os.environ.get("VARKODER_AMD_PER_FILE_STATS"):   # (tests: this rank's per-file rows, before they are folded)
+            import json
+            with open(os.environ["VARKODER_AMD_PER_FILE_STATS"] + f".rank{rank}.json", "w") as f:
+                json.dump(per_file, f)
+        for key, st in per_file.items():
+            s = mine[key.split(SAMPLE_BP_SEP)[0]]
+            for name in (ck, ik):
+                if name in st:
+                    s[name] = s.get(name, 0) + st[name]
+            if "failed_step" in st:
+                s["failed_step"] = st["failed_step"]
+        for name, st in mine.items():
+            st["base_frequencies_sd"] = base_sd.get(name, 0)
+    except Exception as e:   # noqa: BLE001 -- reported by finish_image_job, once every rank is past its collectives
+        error = e
+    finish_image_job(args, outdir, rank, world, mine, error, samples, labels, base_sd)
 
 
 def main(argv=None):

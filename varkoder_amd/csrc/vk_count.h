@@ -1289,6 +1289,9 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         };
 
         // context of the next granule or block to be counted: codes and BAD of the 16 positions before it
+        // (round 6: in vector registers, of which LANE 0 is what counts: the heavy stage shifts it in with the same DPP move
+        // that fetches every other lane's neighbour, and a full round leaves its lane 63 there with one wave_ror -- a
+        // v_readlane into a scalar and a v_mov back out of it per value and round before)
         uint32_t ctx_c = 0u, ctx_bad = 0x55555555u;
         uint32_t pph = 0;     // line phase at the start of the current piece
         uint32_t npend = 0;   // granules waiting in xb[0 .. npend), < 64 between pieces
@@ -1306,19 +1309,32 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
 
         // The heavy stage on one granule per lane (the first n lanes; the others idle along on a granule
         // of newlines): q = xb[lane].  probe: also look whether the data has turned low-complexity.
-        auto round_count = [&](uint32_t n, uint4 q, bool probe) __attribute__((always_inline)) {
+        auto round_count = [&](uint32_t n, uint4 q, bool probe, bool full = true) __attribute__((always_inline)) {
 #ifdef VK_DIAG_NO_HEAVY
             asm volatile("" :: "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
             return;
 #endif
-            uint32_t C, IV, SEQ;
-            vkl::classify_granule(q.x & ~vkl::kGranuleStartTag, q.y, q.z, q.w, (q.x & vkl::kGranuleStartTag) != 0u, C, IV, SEQ);
+            uint32_t C, bad, SEQ;   // (bad: even bits; the odd ones hold garbage that ok_mask1 drops)
+            vkl::classify_granule_note(q.x, q.y, q.z, q.w, C, bad, SEQ);
             if constexpr (INDEX) nsite += vkl::popc(SEQ & 0x55555555u);
-            const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
-            const uint32_t badh = wave_prev_lane(bad, ctx_bad);
-            const uint32_t ch = wave_prev_lane(C, ctx_c);
-            ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bad), static_cast<int>(n - 1u)));
-            ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(C), static_cast<int>(n - 1u)));
+            uint32_t badh = ctx_bad, ch = ctx_c;   // (lane 0 keeps these: wave_shr:1 has no source for it)
+            if (full) {   // n = 64: the neighbours, and lane 63 into lane 0 of the context (wave_ror:1) -- in this order, by hand:
+                          // hipcc put the rotation first and paid a copy of the old context for it
+                uint32_t nb, nc;
+                asm("s_nop 1\n\t"
+                    "v_mov_b32_dpp %0, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_mov_b32_dpp %1, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_mov_b32_dpp %2, %4 wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_mov_b32_dpp %3, %5 wave_ror:1 row_mask:0xf bank_mask:0xf"
+                    : "+v"(badh), "+v"(ch), "=&v"(nb), "=&v"(nc) : "v"(bad), "v"(C));
+                ctx_bad = nb;
+                ctx_c = nc;
+            } else {
+                badh = wave_prev_lane(bad, ctx_bad);
+                ch = wave_prev_lane(C, ctx_c);
+                ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bad), static_cast<int>(n - 1u)));
+                ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(C), static_cast<int>(n - 1u)));
+            }
             const uint32_t ok = vkl::ok_mask1<K>(badh, bad);
             uint32_t pa;
             unsigned long long pm;
@@ -1326,10 +1342,10 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
             if (probe) hot = probe_low_complexity(pa, pm, tick);
         };
         auto flush = [&]() __attribute__((always_inline)) {  // the pending granules, before a piece takes the general path
-            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
+            uint4 q = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au | vkl::kGranuleEnd, 0x0A0A0A0Au, 0x0A0A0A0Au);   // (note: no sequence bytes)
             const uint32_t ln = lane_now();
             if (ln < npend) q = xb[ln];
-            round_count(npend, q, true);
+            round_count(npend, q, true, false);
             npend = 0u;
         };
 
@@ -1370,7 +1386,9 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 total = lane_bcast(incl, 63);
                 const uint32_t lph = (pph + incl - c) & 3u;
                 uint32_t s_raw;
-                const bool plain = vkl::seq_span(mlo, mhi, c, lph, s, e, s_raw);
+                // (one note per lane: a stretch that starts inside a granule AND ends in this lane -- a read under 64 bases --
+                // is set aside like the shapes seq_span itself refuses)
+                const bool plain = vkl::seq_span_note(mlo, mhi, c, lph, s, e, s_raw);
                 const unsigned long long am = __ballot(!plain);
                 if (am != 0ull) {   // rare: lanes set aside (see above), or too many of them
                     const uint32_t na = static_cast<uint32_t>(__builtin_popcountll(am));
@@ -1389,11 +1407,11 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                             // waited for them -- and for this store -- with vmcnt(0): 6 % of wave time on fastp-shaped reads)
                             const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(alist, 0, static_cast<int>(aside_cap * 4u), 0x00020000);
                             __builtin_amdgcn_raw_buffer_store_b32(((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph, arsrc, (naside + below) * 4u, 0, 0);
-                            uint32_t nl4;   // the separator (made here: as a loop invariant hipcc kept the constant in scratch)
-                            asm volatile("v_mov_b32 %0, 0x0a0a0a0a" : "=v"(nl4));
-                            r0 = make_uint4(nl4, nl4, nl4, nl4);
+                            // the separator: the lane's first granule as it is, under the note "the line ends at position 0" --
+                            // no sequence bytes, whatever the bytes are (until round 6 the granule was overwritten with
+                            // newlines: a write to the piece's registers in a branch, four moves on every piece's way)
                             s = 0u;
-                            e = 15u;
+                            e = 0u;
                         }
                         naside = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(naside + na)));   // (kept in a scalar register)
                     }
@@ -1430,7 +1448,9 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 if (npend != 0u) flush();
                 ++ngeneral;
                 GeneralState gs;
-                gs.ctx_c = ctx_c; gs.ctx_bad = ctx_bad; gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
+                gs.ctx_c = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ctx_c)));
+                gs.ctx_bad = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ctx_bad)));
+                gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
                 gs.nanch = nanch; gs.full = 0u; gs.sites = 0u;
                 const uint32_t valid = (it + 1 == npieces && tail_bytes != 0u) ? tail_bytes : static_cast<uint32_t>(kPiece);
                 gs = general_piece<K, INDEX>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u) | (ph0 << 2) | (valid << 4),
@@ -1448,24 +1468,62 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 total = 0u;   // (pph is the general path's)
             } else {
                 // ---- hand the granules with sequence bytes to the heavy stage, 64 at a time ----
-                const uint32_t gs = vkl::span_first(s), n = vkl::span_count(s, e);
+                // (s = 64 comes with e = 64: gs = 4, one past the last granule = 4, n = 0)
+                const uint32_t gs = vkl::span_first(s), n = ((vkl::umin(e, 63u) + 16u) >> 4) - gs;
                 const uint32_t incl = wave_inclusive_sum(n);
                 tot = npend + lane_bcast(incl, 63);
-                const uint32_t first = npend + incl - n - gs;  // + g = the granule's place in the stream (64 per round)
-                // place and round of every granule of this lane (0xFFFF....: none of its rounds)
-                uint32_t wp[4];
+                const uint32_t mine0 = npend + incl - n;   // place in the stream (64 per round) of this lane's first granule
+                const uint32_t first = mine0 - gs;         // + g = the place of its granule g
+                // round and buffer address of every granule of this lane (round kNoRound: none of its rounds)
+                constexpr uint32_t kNoRound = 0x03FFFFFFu;
+                const uint32_t xb_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)xb));
+                uint32_t rd[5], ad[5];
+                uint32_t xbv;   // (the base in a vector register: v_lshl_add takes one scalar operand at most, and the shift is one)
+                asm("v_mov_b32 %0, %1" : "=v"(xbv) : "s"(xb_base));
 #pragma unroll
-                for (uint32_t g = 0; g < 4; ++g) wp[g] = (g - gs < n) ? first + g : 0xFFFFFFC0u;
-                // the start tag is set on the granule's copy in the buffer (the piece's registers stay as loaded:
-                // four aligned 128-bit tuples the stores can take as they are)
-                const uint32_t wtag = vkl::span_starts_inside(s) ? first + gs : 0xFFFFFFC0u;
+                for (uint32_t g = 0; g < 4; ++g) {
+                    const uint32_t place = first + g;
+                    rd[g] = (g - gs < n) ? place >> 6 : kNoRound;
+                    ad[g] = vkl::lshl_add(place & 63u, 4, xbv);
+                }
+                // The note of the stretch's edge granule (vk_lane.h, classify_granule_note) is set on the granule's copy in the
+                // buffer (the piece's registers stay as loaded: four aligned 128-bit tuples the stores can take as they are):
+                // where the first base is (s & 15 != 0), else where the line ends (e < 64); never both (span_one_note), so
+                // one of s & 15 and e & 15 is zero (a stretch that starts inside a granule runs on: e = 64).
+                const bool has_s = (s & 15u) != 0u;        // (s = 64: no)
+                const uint32_t pnote = has_s ? mine0 : (e < 64u ? mine0 + n - 1u : 0xFFFFFFC0u);
+                rd[4] = pnote >> 6;
+                ad[4] = vkl::lshl_add(pnote & 63u, 4, xbv);
+                const uint32_t note_lo = vkl::note_spread((s | e) & 15u), note_hi = has_s ? 0u : vkl::kGranuleEnd;
                 const uint32_t rounds = tot >> 6;
-                auto put = [&](uint32_t r) __attribute__((always_inline)) {  // the granules whose round is r
-                    if ((wp[0] >> 6) == r) xb[wp[0] & 63u] = r0;
-                    if ((wp[1] >> 6) == r) xb[wp[1] & 63u] = r1;
-                    if ((wp[2] >> 6) == r) xb[wp[2] & 63u] = r2;
-                    if ((wp[3] >> 6) == r) xb[wp[3] & 63u] = r3;
-                    if ((wtag >> 6) == r) atomicOr(&xb[wtag & 63u].x, vkl::kGranuleStartTag);
+                // put(r): the granules whose round is r go into the buffer, the note behind them.  Hand-written (the
+                // compiler's version: a compare, a saved exec mask, a branch around the store and a restored mask per
+                // slot -- ~46 scalar instructions and 15 branches per piece): five lane masks, then five {exec; LDS op}.
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                auto put = [&](uint32_t r) __attribute__((always_inline)) {
+                    const u32x4 g0 = {r0.x, r0.y, r0.z, r0.w}, g1 = {r1.x, r1.y, r1.z, r1.w};
+                    const u32x4 g2 = {r2.x, r2.y, r2.z, r2.w}, g3 = {r3.x, r3.y, r3.z, r3.w};
+                    const u32x2 nt = {note_lo, note_hi};
+                    unsigned long long m0, m1, m2, m3, m4;
+                    const unsigned long long exec_in = __builtin_amdgcn_read_exec();
+                    asm volatile(
+                        "v_cmp_eq_u32_e64 %0, %5, %15\n\t"
+                        "v_cmp_eq_u32_e64 %1, %6, %15\n\t"
+                        "v_cmp_eq_u32_e64 %2, %7, %15\n\t"
+                        "v_cmp_eq_u32_e64 %3, %8, %15\n\t"
+                        "v_cmp_eq_u32_e64 %4, %9, %15\n\t"
+                        "s_mov_b64 exec, %0\n\tds_write_b128 %10, %16\n\t"
+                        "s_mov_b64 exec, %1\n\tds_write_b128 %11, %17\n\t"
+                        "s_mov_b64 exec, %2\n\tds_write_b128 %12, %18\n\t"
+                        "s_mov_b64 exec, %3\n\tds_write_b128 %13, %19\n\t"
+                        "s_mov_b64 exec, %4\n\tds_or_b64 %14, %20\n\t"
+                        "s_mov_b64 exec, %21"
+                        : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4)
+                        : "v"(rd[0]), "v"(rd[1]), "v"(rd[2]), "v"(rd[3]), "v"(rd[4]),
+                          "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "s"(r),
+                          "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(nt), "s"(exec_in)
+                        : "memory");
                 };
                 // The last two rounds' granules are taken out of the buffer first, so that the piece's registers are
                 // free -- and the next piece's loads in flight -- under the arithmetic of BOTH rounds (-0.5 % on 512

@@ -120,6 +120,17 @@ VKL_FN uint32_t lshl_or(uint32_t a, uint32_t sh, uint32_t c) {
 #endif
 }
 
+// (a << sh) + c as one instruction; sh must fold to a constant
+VKL_FN uint32_t lshl_add(uint32_t a, uint32_t sh, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "v"(c));
+    return d;
+#else
+    return (a << sh) + c;
+#endif
+}
+
 struct LaneBits {
     uint32_t C[4];
     uint32_t IV[4];
@@ -616,6 +627,84 @@ VKL_FN void classify_granule(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
     Cout = C;
     IVout = IV;
     SEQout = starts_inside ? ~((low << 2) | 3u) : low;
+}
+
+// ---- round 6: the line pass tells the heavy stage where a granule's sequence bytes are ------------------------
+// The line pass knows every lane's stretch [s, e] already; classify_granule() found it again from the granule's own
+// newline flags (four v_xad, four shifts, four v_and_or, the mask below the first newline and a select: 21 of the
+// heavy stage's 116 vector instructions per round).  Now the two EDGE granules of a stretch carry a 5-bit note in
+// bit 7 of their first five bytes (the bytes are ASCII: bit 7 is free; the classification below does not look at it):
+//   bytes 0..3  p, a position 0..15, one bit per byte (bit i of p on byte i)
+//   byte 4      kGranuleEnd: the sequence bytes are the positions BELOW p (p = the newline that ends the line);
+//               clear: the positions FROM p on (p = s & 15, the first base; 0 = all sixteen: a granule without a
+//               note is all sequence).
+// A separator granule (sixteen newlines) needs no note: a newline is not a base.
+constexpr uint32_t kGranuleNoteBits = 0x80808080u;   // dword 0: p
+constexpr uint32_t kGranuleEnd = 0x80u;              // dword 1
+
+// bit i of p (0..15) on bit 7 of byte i
+VKL_FN uint32_t note_spread(uint32_t p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t;   // (spelled out: hipcc folds the shift into the factor and takes the quarter-rate v_mul_lo_u32 for it)
+    asm("v_mul_u32_u24 %0, 0x204081, %1" : "=v"(t) : "v"(p));
+    return (t & 0x01010101u) << 7;
+#else
+    return ((p * 0x204081u) & 0x01010101u) << 7;
+#endif
+}
+
+// One note per lane: a stretch may start inside a granule, or end in the lane, not both.
+VKL_FN bool span_one_note(uint32_t s, uint32_t e) { return (s & 15u) == 0u || e >= 64u; }
+
+// seq_span() for the note scheme: the same stretch [s, e], and what one note per lane can describe -- seq_span's two
+// granule rules (start and end in one granule; two line ends in front of a start) were the tag's limits and are
+// gone: the note names the position itself.  What stays: at most three newlines (two when two or three line ends
+// must pass first: the candidates stop at the second newline), and span_one_note.
+VKL_FN bool seq_span_note(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e, uint32_t& s_raw) {
+    const uint32_t dn = (1u - lph) & 3u;
+    const uint32_t p1 = first_bit64(lo, hi);
+    const uint32_t lo1 = lo & (lo - 1u), hi1 = lo ? hi : (hi & (hi - 1u));
+    const uint32_t p2 = first_bit64(lo1, hi1);
+    const uint32_t cand = 0xFFu | (p1 << 8) | (p2 << 16) | (64u << 24);
+    const uint32_t pr = alignbit(64u, cand, 8u * dn);
+    s_raw = (pr + 1u) & 0xFFu;
+    s = umin(s_raw, 64u);
+    e = (pr >> 8) & 0xFFu;
+    return c <= (dn >= 2u ? 2u : 3u) && span_one_note(s, e);
+}
+
+// Heavy stage, one all-ASCII granule with its note: codes (2-bit geometry) and BAD -- not a base of the sequence
+// line -- on the EVEN bits (the odd bits hold garbage: every user shifts by whole positions and masks at the end).
+// seq (both bits of a position, for the read index): the positions the note calls sequence bytes.
+VKL_FN void classify_granule_note(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& Cout, uint32_t& BADout, uint32_t& SEQout) {
+    constexpr uint32_t kLutLo = 0x41204020u, kLutHi = 0x42202053u;  // as in classify()
+    const uint32_t p01l = perm(a1, a0, 0x05010400u), p01h = perm(a1, a0, 0x07030602u);
+    const uint32_t p23l = perm(a3, a2, 0x05010400u), p23h = perm(a3, a2, 0x07030602u);
+    const uint32_t T[4] = {perm(p23l, p01l, 0x05040100u), perm(p23l, p01l, 0x07060302u),
+                           perm(p23h, p01h, 0x05040100u), perm(p23h, p01h, 0x07060302u)};
+    uint32_t C = 0, IV = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t t = T[j];
+        const uint32_t L = perm(kLutHi, kLutLo, t & 0x07070707u);
+        const uint32_t x = xor_and_k(L, t, 0x58585858u);   // (bit 7 left out: the note; x < 0x80, the add below never carries)
+        C = j == 0 ? (x & 0x03030303u) : lshl_or(x & 0x03030303u, 2 * j, C);
+        const uint32_t nz = x + 0x7C7C7C7Cu;
+        IV = j == 0 ? ((nz >> 7) & 0x01010101u) : and_or_k(nz >> (7 - 2 * j), 0x01010101u << (2 * j), IV);
+    }
+    const uint32_t m = udot4(a0 & kGranuleNoteBits, 0x20100804u, 0u);   // p << 9
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t S;   // all ones: an end granule (one v_bfe_i32; hipcc makes it v_bfe_u32 + v_add)
+    asm("v_bfe_i32 %0, %1, 7, 1" : "=v"(S) : "v"(a1));
+#else
+    const uint32_t S = static_cast<uint32_t>(static_cast<int32_t>(a1 << 24) >> 31);
+#endif
+    const uint32_t X = 0xFFFFFFFFu << ((m >> 8) & 31u);                  // positions from p on
+    Cout = C;
+    SEQout = X ^ S;
+    BADout = IV | ~(X ^ S);
 }
 
 // The same for any bytes (no ASCII precondition), with the newline flags instead of a sequence mask: the subsample

@@ -14,7 +14,7 @@ from pathlib import Path
 
 from .config import QUAL_THRESH
 from .image import counts_name, eprint, png_name, shard_folder, write_png
-from .shard import file_weights, shard_by_size
+from .shard import agreed_weights, shard_by_size
 
 
 # Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
@@ -33,11 +33,13 @@ def image_name(fastq_path, k, mapping_code):
 
 def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_sd=None, overwrite=False,
                      subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=None, io_threads=8,
-                     engine=None, verbose=False, timings=None):
+                     engine=None, verbose=False, timings=None, weights=None):
     """Process this rank's share of `files`.  Returns {sample_file_stem: OrderedDict(stats)}
     with the reference's stats keys `<k>mer_counting_time` and `k<k>_img_time` (per-file
     share of the batch wall time) or `failed_step` for files whose FASTQ framing is bad.
     batch_bytes: None = DEFAULT_BATCH_BYTES (DEFAULT_GZ_BATCH_BYTES when every file is gzip).
+    weights: the files' work estimates as every rank of the job uses them (shard.agreed_weights -- a collective: pass them in
+    when this call sits in a try block that a failing rank would leave early); None: agreed on here.
     timings: optional dict that receives where this thread's wall time went (seconds): waiting for the
     staging thread (`stage_wait_s`), the copy to the device and the inflate (`upload_s`, of which
     `inflate_s`), kernels + copies back (`kernels_s`) and waiting for the last hand-overs and PNGs (`png_tail_s`);
@@ -46,7 +48,9 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     files = [Path(f) for f in files]
     labels = labels or {}
     base_sd = base_sd or {}
-    mine = [files[i] for i in shard_by_size(file_weights(files), rank, world)]   # size-aware: see shard.shard_by_size
+    if weights is None:
+        weights = agreed_weights(files)
+    mine = [files[i] for i in shard_by_size(weights, rank, world)]   # size-aware; rank 0's view of the sizes: see shard.agreed_weights
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)
@@ -87,59 +91,69 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     # thread, into the other of two staging buffers, while this thread copies and processes.
     stager = ThreadPoolExecutor(1)
     finisher, handed = ThreadPoolExecutor(1), []
-    staged = stager.submit(eng.stage_files, batches[0][0], pool, 0) if batches else None
-    for bi, (batch, nbytes) in enumerate(batches):
-        t0 = time.perf_counter()
-        ready = staged.result()
-        tm["stage_wait_s"] += time.perf_counter() - t0
-        if bi + 1 < len(batches):
-            staged = stager.submit(eng.stage_files, batches[bi + 1][0], pool, (bi + 1) & 1)
-        tu = time.perf_counter()
-        dev, offs, lens = eng.upload_staged(ready, timings=tm)
-        t1 = time.perf_counter()
-        tm["upload_s"] += t1 - tu
-        img, hist, status = eng.fastq_to_images(dev, offs, lens)
-        st = status.cpu().numpy()
-        imgs = img.cpu().numpy()
-        nz = (hist != 0).any(dim=1).cpu().numpy()
-        t2 = time.perf_counter()
-        tm["kernels_s"] += t2 - t1
+    done = False
+    try:
+        staged = stager.submit(eng.stage_files, batches[0][0], pool, 0) if batches else None
+        for bi, (batch, nbytes) in enumerate(batches):
+            t0 = time.perf_counter()
+            ready = staged.result()
+            tm["stage_wait_s"] += time.perf_counter() - t0
+            if bi + 1 < len(batches):
+                staged = stager.submit(eng.stage_files, batches[bi + 1][0], pool, (bi + 1) & 1)
+            for h in handed:   # a hand-over that failed (a folder that cannot be made) stops the pass here, not after the last batch
+                if h.done() and h.exception() is not None:
+                    raise h.exception()
+            tu = time.perf_counter()
+            dev, offs, lens = eng.upload_staged(ready, timings=tm)
+            t1 = time.perf_counter()
+            tm["upload_s"] += t1 - tu
+            img, hist, status = eng.fastq_to_images(dev, offs, lens)
+            st = status.cpu().numpy()
+            imgs = img.cpu().numpy()
+            nz = (hist != 0).any(dim=1).cpu().numpy()
+            t2 = time.perf_counter()
+            tm["kernels_s"] += t2 - t1
 
-        def hand_over(batch=batch, st=st, imgs=imgs, nz=nz, per_file=(t2 - t0) / len(batch)):
-            # stats rows and PNG jobs of one batch: on a thread of its own (batches in order), beside the next batch's
-            # upload and inflate, in whose C calls this thread's interpreter lock is free (9 % of a .fq.gz pass before)
-            th = time.perf_counter()
-            for j, f in enumerate(batch):
-                key = str(f.name.removesuffix("".join(f.suffixes)))
-                s = stats.setdefault(key, OrderedDict())
-                if st[j] or not nz[j]:
-                    eprint("K-MER COUNTING FAIL, SKIPPING FILE:", f)
-                    s["failed_step"] = "image"
-                    continue
-                s[str(k) + "mer_counting_time"] = per_file
-                d, name = target(f)
-                d.mkdir(parents=True, exist_ok=True)
-                sample = key.split("@")[0]
-                sd = base_sd.get(sample, 0)
-                pending.append((key, time.perf_counter(),
-                                pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
-                                            QUAL_THRESH, mapping_code)))
-            tm["png_submit_s"] += time.perf_counter() - th   # (this thread's time: off the main thread's path)
+            def hand_over(batch=batch, st=st, imgs=imgs, nz=nz, per_file=(t2 - t0) / len(batch)):
+                # stats rows and PNG jobs of one batch: on a thread of its own (batches in order), beside the next batch's
+                # upload and inflate, in whose C calls this thread's interpreter lock is free (9 % of a .fq.gz pass before)
+                th = time.perf_counter()
+                for j, f in enumerate(batch):
+                    key = str(f.name.removesuffix("".join(f.suffixes)))
+                    s = stats.setdefault(key, OrderedDict())
+                    if st[j] or not nz[j]:
+                        eprint("K-MER COUNTING FAIL, SKIPPING FILE:", f)
+                        s["failed_step"] = "image"
+                        continue
+                    s[str(k) + "mer_counting_time"] = per_file
+                    d, name = target(f)
+                    d.mkdir(parents=True, exist_ok=True)
+                    sample = key.split("@")[0]
+                    sd = base_sd.get(sample, 0)
+                    pending.append((key, time.perf_counter(),
+                                    pool.submit(write_png, imgs[j].copy(), d / name, labels.get(sample, []), sd,
+                                                QUAL_THRESH, mapping_code)))
+                tm["png_submit_s"] += time.perf_counter() - th   # (this thread's time: off the main thread's path)
 
-        handed.append(finisher.submit(hand_over))
-        if verbose:
-            eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
-    stager.shutdown()
-    tt = time.perf_counter()
-    for h in handed:
-        h.result()   # (an exception of a batch's hand-over surfaces here)
-    finisher.shutdown()
-    for key, t, fut in pending:
-        fut.result()
-        stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t
+            handed.append(finisher.submit(hand_over))
+            if verbose:
+                eprint(f"batch of {len(batch)} files, {nbytes} bytes: upload {t1 - t0:.3f}s kernels {t2 - t1:.3f}s")
+        tt = time.perf_counter()
+        for h in handed:
+            h.result()   # (an exception of a batch's hand-over surfaces here)
+        for key, t, fut in pending:
+            fut.result()
+            stats[key]["k" + str(k) + "_img_time"] = time.perf_counter() - t
+        done = True
+    finally:
+        # An error anywhere above (a copy that runs out of memory, a PNG that cannot be written) must not leave the staging
+        # thread reading the next batch or queued hand-overs writing PNGs into outdir behind the caller's back.
+        for ex in (stager, finisher, pool):
+            ex.shutdown(wait=True, cancel_futures=not done)
+        if not done and engine is None:
+            eng.close()
     tm["png_tail_s"] += time.perf_counter() - tt
     tm["batches"] = tm.get("batches", 0) + len(batches)
-    pool.shutdown()
     if engine is None:
         eng.close()
     return stats
@@ -147,7 +161,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
 
 def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp=None, is_query=False, seeds=None,
                     labels=None, base_sd=None, subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=None,
-                    io_threads=8, engine=None, verbose=False):
+                    io_threads=8, engine=None, verbose=False, weights=None):
     """Steps C+D+E of run_clean2img (commands/image.py:1006-1127) for cleaned, UNSPLIT read files
     `<sample>.fq[.gz]` (the reference's `<int_folder>/clean_reads/`): the 1-2-5 ladder of subsamples
     is drawn on the GPU (subsample.ladder_counts) instead of writing one file per size with
@@ -163,7 +177,9 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
     from .subsample import ladder_counts, split_name
     files = [Path(f) for f in files]
     labels, base_sd, seeds = labels or {}, base_sd or {}, seeds or {}
-    mine = [files[i] for i in shard_by_size(file_weights(files), rank, world)]   # size-aware: see shard.shard_by_size
+    if weights is None:
+        weights = agreed_weights(files)   # (a collective: see fastqs_to_images)
+    mine = [files[i] for i in shard_by_size(weights, rank, world)]   # size-aware; rank 0's view of the sizes: see shard.agreed_weights
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)

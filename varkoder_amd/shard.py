@@ -119,27 +119,72 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
-def gather_stats(local_stats, dst=0):
-    """Merge {sample: OrderedDict(...)} dicts of all ranks on rank `dst` (others get None),
-    the counterpart of process_stats' all_stats.update (commands/image.py:1167-1168)."""
+def merge_stats(parts):
+    """Fold the ranks' {sample: OrderedDict(stats)} dicts into one, the way run_clean2img accumulates a sample's
+    stats while it walks the sample's files (commands/image.py:1078: `stats[k] = stats.get(k, 0) + v` for the
+    timings; :1070-1075: a failed step is recorded and stays).  Files are dealt by size (shard_by_size), so the
+    rungs of ONE sample's ladder land on different ranks by design: a `*_time` value is the SUM over the ranks
+    that held a file of the sample, `failed_step` survives whichever rank reported it (the first in rank order
+    when several did), every other key (`base_frequencies_sd`, `splitting_bp_per_file`: the same on every rank
+    that has it) is taken from the last rank that holds it."""
+    merged = OrderedDict()
+    for part in parts:
+        for name in sorted(part or {}):
+            row = merged.setdefault(name, OrderedDict())
+            for key, val in part[name].items():
+                if key.endswith("_time") and key in row:
+                    row[key] = row[key] + val
+                elif key == "failed_step" and key in row:
+                    continue
+                else:
+                    row[key] = val
+    return OrderedDict(sorted(merged.items()))
+
+
+def gather_stats(local_stats, dst=0, error=None, with_errors=False):
+    """Merge {sample: OrderedDict(...)} dicts of all ranks on rank `dst` (others get None) with merge_stats,
+    the counterpart of process_stats' all_stats.update (commands/image.py:1167-1168).
+
+    error: what went wrong on THIS rank (a string), or None.  It travels with the rank's dict, so a rank whose
+    work raised still takes part in the collective -- a rank that stayed away would leave the others blocked
+    here until the backend's timeout (the reference's pool loses one sample when a worker dies,
+    commands/image.py:1281-1284, never the whole run).  with_errors: return (merged, [errors of all ranks])
+    -- on `dst`; (None, None) elsewhere with gloo; every rank gets both under nccl (all_gather)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return OrderedDict(local_stats)
+        merged = merge_stats([local_stats])
+        return (merged, [error] if error else []) if with_errors else merged
     rank, world = dist.get_rank(), dist.get_world_size()
+    mine = (dict(local_stats), error)
     if dist.get_backend() == "nccl":
         # object collectives need CPU tensors: all_gather_object handles the device hop itself
         bucket = [None] * world
-        dist.all_gather_object(bucket, dict(local_stats))
+        dist.all_gather_object(bucket, mine)
     else:
         bucket = [None] * world if rank == dst else None
-        dist.gather_object(dict(local_stats), bucket, dst=dst)
+        dist.gather_object(mine, bucket, dst=dst)
     if rank != dst:
-        return None
-    merged = OrderedDict()
-    for part in bucket:
-        for k in sorted(part):
-            merged.setdefault(k, OrderedDict()).update(part[k])
-    return OrderedDict(sorted(merged.items()))
+        return (None, None) if with_errors else None
+    merged = merge_stats([part for part, _ in bucket])
+    errors = [e for _, e in bucket if e]
+    return (merged, errors) if with_errors else merged
+
+
+def agreed_weights(files, src=0):
+    """file_weights(files) as EVERY rank of the job will use them: rank `src` looks at the files and broadcasts
+    what it saw (control plane: one small object).  shard_by_size is only a partition when all ranks feed it
+    the same numbers, and two ranks that stat a file a moment apart -- one still being written, an NFS
+    attribute cache, another node -- need not see the same size: files would be imaged twice, or by nobody,
+    without an error.  Without a process group: this process's own view."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return file_weights(files)
+    box = [file_weights(files) if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    if len(box[0]) != len(files):
+        raise RuntimeError("ranks disagree about the list of input files (%d here, %d on rank %d)"
+                           % (len(files), len(box[0]), src))
+    return box[0]
 
 
 def split_at_records(data, nparts, window=1 << 16):

@@ -411,6 +411,7 @@ def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=180.0):
     for drop in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE"):
         env.pop(drop, None)
     total = {}
+    child_ms = {}
     with tempfile.TemporaryDirectory(prefix="vk_traffic_", dir="/tmp") as tmp:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
@@ -426,6 +427,11 @@ def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=180.0):
                         path = os.path.join(root, f)
             if r.returncode != 0 or path is None:
                 return None, "rocprofv3 child: rc %d, %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])
+            try:   # the child's own bench line: its launch time under the counters, beside the timed steps' of this process
+                line = json.loads(r.stdout.decode(errors="replace").strip().splitlines()[-1])
+                child_ms[ctr] = float(line["roofline"]["avg_launch_ms"])
+            except Exception:  # noqa: BLE001
+                child_ms[ctr] = None
             per_kernel = {}
             with open(path) as f:
                 for row in csv.DictReader(f):
@@ -437,7 +443,9 @@ def live_traffic(args, k, mapping, samples, pool, dist_code, timeout=180.0):
             total[ctr] = sum(sum(v) / len(v) for v in per_kernel.values())
     return total["FETCH_SIZE"] * 1024 * 2 + total["WRITE_SIZE"] * 1024, \
         "measured_in_this_run (this script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate child processes, the same " \
-        "configuration; FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)"
+        "configuration; FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md); the children's own count launch under the counters took " \
+        "%s / %s ms (avg_launch_ms of this line: the timed steps of this process)" % tuple(
+            "%.2f" % child_ms[c] if child_ms.get(c) else "?" for c in ("FETCH_SIZE", "WRITE_SIZE"))
 
 
 def ladder_shard(eng, args, rank, world, dist, red_dev):
@@ -969,6 +977,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": count_ms,
+                         "count_ms_by_step": [float(e[0].elapsed_time(e[1])) for e in ev],
                          "traffic_source": "from_profile_file (profiles/traffic_latest.json: separate rocprofv3 --pmc passes "
                                            "of this configuration); achieved / avg_launch_ms are this run's HIP events"},
         }
@@ -1022,7 +1031,10 @@ def main():
         under_profiler = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES")) or \
             any(v.startswith(("ROCPROF", "ROCPROFILER")) for v in os.environ)
         if world == 1 and not args.no_live_traffic and not under_profiler:
-            # roofline.traffic measured in THIS run (the sample pools of every leg above are freed by now)
+            # roofline.traffic measured in THIS run: the sample pools of every leg above are freed by now, and so is this
+            # process's engine (its workspaces would sit beside the children's on the card)
+            eng.close()
+            eng = None
             torch.cuda.empty_cache()
             t0 = time.perf_counter()
             try:
@@ -1056,7 +1068,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
     if bad:
         sys.exit(3)
 

@@ -466,3 +466,64 @@ def test_overflow_retries_never_shrink_the_slot_and_mapped_files_are_released(en
         assert int(lens[0]) == len(a) + len(b), route
         assert bytes(dev.cpu().numpy()[int(offs[0]):int(offs[0]) + int(lens[0])]) == a + b, route
         assert int(eng.last_upload_status[0]) == 0
+
+
+def test_sources_just_behind_the_history_across_block_kinds(engines):
+    """The slab resolver takes a source at most ~448 positions back from its LDS history and anything further from the text
+    in memory, four slabs' loads at once behind a counted wait for this wavefront's older stores (csrc/vk_inflate.h,
+    gz_resolve_slabs: vmcnt(7)).  Streams made for the seam: every unit repeats text 513..600 positions back (just behind
+    the 512-element history), the next one text under 448 back, on and on -- through dynamic blocks, stored blocks (which go
+    around the history) and full flushes in between, and with the short token groups that flushes end in; small files (one
+    wavefront, text bytes) and large ones (chunk decoder, u16 elements with the unknown window).  Byte-exact against zlib,
+    every member's CRC checked on the device."""
+    eng = engines(7)
+    rng = np.random.default_rng(606)
+
+    def seam_text(n, seed):
+        r = np.random.default_rng(seed)
+        out = bytearray(r.integers(65, 91, size=700, dtype=np.uint8).tobytes())
+        far = True
+        while len(out) < n:
+            d = int(r.integers(513, 601)) if far else int(r.integers(3, 449))
+            ln = int(r.integers(4, 40))
+            start = len(out) - d
+            for i in range(ln):            # (byte by byte: an overlapping copy when ln > d)
+                out.append(out[start + i])
+            out.extend(r.integers(65, 91, size=int(r.integers(0, 3)), dtype=np.uint8).tobytes())   # a literal or two between
+            far = not far
+        return bytes(out[:n])
+
+    def mixed_stream(text, level, seed):
+        """one gzip member whose blocks alternate: dynamic (or fixed) / stored / sync- and full-flushed pieces"""
+        r = np.random.default_rng(seed)
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 9)
+        out, pos = [], 0
+        while pos < len(text):
+            n = int(r.integers(900, 9000))
+            piece = text[pos:pos + n]
+            pos += n
+            kind = int(r.integers(0, 4))
+            out.append(co.compress(piece))
+            if kind == 0:
+                out.append(co.flush(zlib.Z_SYNC_FLUSH))     # ends the block, an empty stored block behind it
+            elif kind == 1:
+                out.append(co.flush(zlib.Z_FULL_FLUSH))     # the same, and the next block may not look back
+            elif kind == 2:                                 # a real stored block: incompressible bytes in between
+                noise = r.integers(0, 256, size=int(r.integers(100, 700)), dtype=np.uint8).tobytes()
+                out.append(co.compress(noise))
+                out.append(co.flush(zlib.Z_SYNC_FLUSH))
+                text = text[:pos] + noise + text[pos:]
+                pos += len(noise)
+        out.append(co.flush())
+        return b"".join(out), text
+
+    files, wants = [], []
+    for i, (n, level) in enumerate([(60_000, 1), (60_000, 6), (200_000, 1), (200_000, 9), (3_000_000, 1), (3_000_000, 6)]):
+        f, t = mixed_stream(seam_text(n, 100 + i), level, 200 + i)
+        assert zlib.decompress(f, 31) == t
+        files.append(f)
+        wants.append(t)
+    got, status, _, _ = run(eng, files)
+    assert [int(x) for x in status] == [0] * len(files)
+    for g, w in zip(got, wants):
+        assert g == w

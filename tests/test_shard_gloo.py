@@ -112,10 +112,36 @@ def test_size_aware_shard_balances_unsplit_clean_files(world):
 
 
 def test_file_weights_count_text_bytes(tmp_path):
-    from varkoder_amd import shard
+    """A plain file weighs its bytes; a gzip file the text its own framing names: the size word of a one-member file, the
+    first block's ratio of a BGZF file; members glued together (the last size word says nothing) six times the file."""
+    import gzip
+    import struct
+    import zlib
+    from varkoder_amd import shard, synth
+    text = synth.sample_fastq(5, 4000, 150).tobytes()
     (tmp_path / "a.fq").write_bytes(b"x" * 100)
-    (tmp_path / "b.fq.gz").write_bytes(b"y" * 10)
-    assert shard.file_weights([tmp_path / "a.fq", tmp_path / "b.fq.gz", tmp_path / "missing.fq"]) == [100, 60, 0]
+    (tmp_path / "b.fq.gz").write_bytes(b"y" * 10)                       # (under 18 bytes: not a gzip file)
+    (tmp_path / "one.fq.gz").write_bytes(gzip.compress(text, 1))
+    glued = gzip.compress(text, 6) + gzip.compress(text[:1000], 6)
+    (tmp_path / "glued.fq.gz").write_bytes(glued)
+
+    def bgzf(data, block=30000):
+        out = []
+        for i in list(range(0, len(data), block)) + [None]:
+            piece = b"" if i is None else data[i:i + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = co.compress(piece) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            out.append(b"\x1f\x8b\x08\x04" + b"\0" * 6 + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + body +
+                       struct.pack("<II", zlib.crc32(piece), len(piece)))
+        return b"".join(out)
+    bz = bgzf(text)
+    (tmp_path / "bg.fq.gz").write_bytes(bz)
+    w = shard.file_weights([tmp_path / n for n in ("a.fq", "b.fq.gz", "missing.fq", "one.fq.gz", "glued.fq.gz", "bg.fq.gz")])
+    assert w[:3] == [100, 0, 0]
+    assert w[3] == len(text)
+    assert w[4] == 6 * len(glued)
+    assert abs(w[5] - len(text)) <= 0.1 * len(text)
 
 
 def test_single_process_helpers_are_identity():

@@ -670,7 +670,17 @@ __device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hi
                 int32_t ref[kGzBatch];      // >= 0: the element of that position of this batch (relative to base); kFinal; kFar: raw[k]
                 constexpr int32_t kFinal = -1, kFar = -2;
                 bool any_far = false;
-                __builtin_amdgcn_s_waitcnt(0x0F7F);   // vmcnt(15): the stores of everything behind hist have reached L2
+                // A source in memory (pass 1 below asks for it) lies before ring_lo = b0 - kGzHist or before hist_from.  The store
+                // that wrote the last position before b0 - kGzHist has at least kGzHist / 64 = 8 younger stores of this wave
+                // behind it (a slab's store covers 64 positions at most -- the partial slabs at group ends only add stores), and
+                // everything before hist_from was waited for outright (the stored-block copy ends in vmcnt(0); so does every
+                // block of far loads below).  vmcnt(7): at most the seven youngest vector-memory operations may still be in
+                // flight, so that store has completed.  (Rounds 5 shipped vmcnt(15) with the same comment: by the count that
+                // left the 9th..15th youngest stores -- positions before ring_lo -- possibly outstanding.  No test or soak run
+                // ever read a stale byte: a wavefront's loads and stores of one address are performed in order by the memory
+                // pipeline, which is what a C program's own store -> load relies on without any wait.  The count is now
+                // right on its own; 64 files of 128 MB: the same time.)
+                __builtin_amdgcn_s_waitcnt(0x0F77);   // vmcnt(7), expcnt(7), lgkmcnt(15)
 #pragma unroll
                 for (uint32_t k = 0; k < kGzBatch; ++k) {
                     val[k] = 0u;
@@ -717,12 +727,24 @@ __device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hi
                     // it ends, whatever the compiler does with them next: hipcc waits for a relaxed atomic load, and for a plain
                     // load inside a branch, right behind it, which made a memory round trip of every one of these)
                     static_assert(kGzBatch == 4, "the asm statement below names four loads");
+                    // Every address below is formed from token fields: fenced.  By construction 0 <= p < base + b0 <= cap (asrc >= 0
+                    // was asked above; src < ring_lo <= b0; base + total <= cap), so the fence never fires on a stream that passed
+                    // the distance check -- but an address outside the file's slot must not reach the hand-written loads, whatever
+                    // state this function was entered with (round 5 lost a build -- two resolvers chosen between per call -- to a
+                    // MEMORY_APERTURE_VIOLATION: a wild ADDRESS, which a store still in flight cannot produce; that build is gone,
+                    // the loads that could have taken a garbled position are these).
                     uint64_t a[kGzBatch];
+                    bool wild = false;
 #pragma unroll
                     for (uint32_t k = 0; k < kGzBatch; ++k) {
-                        const long long p = ref[k] == kFar ? static_cast<long long>(base) + static_cast<int32_t>(val[k]) : 0ll;
+                        long long p = ref[k] == kFar ? static_cast<long long>(base) + static_cast<int32_t>(val[k]) : 0ll;
+                        if (static_cast<uint64_t>(p) >= cap) {
+                            wild = wild || ref[k] == kFar;
+                            p = 0;
+                        }
                         a[k] = out_addr + static_cast<uint64_t>(p) * (SYM ? 2u : 1u);
                     }
+                    if (__any(wild)) st |= kGzBadData;
                     if (SYM)
                         asm volatile("global_load_ushort %0, %4, off sc0\n\tglobal_load_ushort %1, %5, off sc0\n\t"
                                      "global_load_ushort %2, %6, off sc0\n\tglobal_load_ushort %3, %7, off sc0\n\ts_waitcnt vmcnt(0)"

@@ -437,14 +437,31 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
     return VK_OK;
 }
 
-uint32_t choose_parts(uint32_t nsamples, uint64_t maxlen) {
-    // The count kernels keep two workgroups per CU resident: 512 slots on the 256 CUs.  A launch of
-    // G equal workgroups runs in ceil(G / 512) rounds, so G just below a multiple of 512 wastes the
-    // least (100 samples: 5 parts = 500 workgroups, not 8 = 800 in two rounds).  Parts never get so
-    // small (< 1 MiB) that the per-wave range sync shows, and a batch that fills the chip several
-    // times over anyway is left alone.
+uint32_t choose_parts(uint32_t nsamples, uint64_t maxlen, int k) {
+    // The count kernels keep two workgroups per CU resident: 512 slots on the 256 CUs.
     constexpr uint64_t kSlots = 512;
-    if (nsamples >= 4 * kSlots) return 1;
+    if (k <= 7) {
+        // Round 6: MANY more workgroups than slots.  Rounds 2-5 launched 1000 samples as 1000 workgroups of 320 MB -- two
+        // "rounds" of the chip in lock-step -- and the wave-cycle counter read 85 % of the launch (profiles/r05a): a
+        // workgroup's slot is held until its slowest wavefront is through its sixteenth of the sample, and a CU that runs
+        // a few per cent behind (another XCD's L2, a busier memory channel) ends the launch alone.  In workgroups of
+        // 10-27 MB the dispatcher hands the faster CUs more of them: 65.6 -> 62.6 ms for 1000 samples, 7.13 -> 6.63 for 100,
+        // 74.1 -> 71.1 on fastp-shaped reads (profiles/ab/r06_parts.txt; flat from 12 to 32 parts, slower again from 64:
+        // every workgroup zeroes and flushes a 64 KB histogram and every wavefront finds its line phase).  At least four
+        // rounds of the chip where that leaves workgroups of 4 MiB.
+        const uint64_t cap4 = maxlen / (4ull << 20) > 1 ? maxlen / (4ull << 20) : 1;
+        uint64_t parts = (maxlen + (8ull << 20)) / (16ull << 20);
+        if (parts < 1) parts = 1;
+        const uint64_t want = (4 * kSlots + nsamples - 1) / nsamples;
+        if (parts < want) parts = want < cap4 ? want : cap4;
+        if (parts > 512) parts = 512;
+        if (nsamples * parts >= 4 * kSlots) return static_cast<uint32_t>(parts);
+    } else if (nsamples >= 4 * kSlots) {
+        return 1;
+    }
+    // Few workgroups after all (a handful of samples; k = 8, 9, whose workspace is sized by the workgroup): a launch of G equal
+    // workgroups runs in ceil(G / 512) rounds, so G just below a multiple of 512 wastes the least (100 samples: 5 parts = 500
+    // workgroups, not 8 = 800 in two rounds).  Parts never get so small (< 1 MiB) that the per-wave range sync shows.
     uint32_t best = 1;
     double best_eff = 0.0;
     for (uint32_t parts = 1; parts <= 512; ++parts) {
@@ -723,7 +740,7 @@ static int count_impl(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets,
         const int rcw = count_walk(ctx, d_fastq, offsets, lengths, nsamples, k, d_hist, d_status, seeds, thresholds, d_sites, &done);
         if (rcw || done) return rcw;
     }
-    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
+    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen, k);
     if (!parts_per_sample && k >= 8 && seeds == nullptr && !ctx->spill_pairs && !ctx->spill_packed) {
         // The quad route's workgroups meet at barriers: twice as many, half as long, when that fills the chip's 512 slots as
         // well (100 samples: 5 -> 10 parts, 500 -> 1000 workgroups), ends a launch with less of a tail: 13.09 against 13.18 ms.
@@ -813,7 +830,8 @@ int index_prepare(vk_ctx* ctx, const void* d_fastq, const uint64_t* offsets, con
         if ((offsets[i] & 15u) != 0) return VK_EINVAL;
         if (lengths[i] > maxlen) maxlen = lengths[i];
     }
-    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen);
+    // (the walker runs a workgroup per (subsample, part) of this split: the rule of rounds 2-5, one round of the chip)
+    uint32_t parts = parts_per_sample ? parts_per_sample : choose_parts(nsamples, maxlen, 9);
     while (maxlen / (static_cast<uint64_t>(parts) * kWaves) >= (1ull << 31)) parts *= 2;
     if (static_cast<uint64_t>(nsamples) * parts > (1u << 24)) return VK_EINVAL;
     const size_t nwaves = static_cast<size_t>(nsamples) * parts * kWaves;

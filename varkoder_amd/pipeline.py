@@ -14,7 +14,7 @@ from pathlib import Path
 
 from .config import QUAL_THRESH
 from .image import counts_name, eprint, png_name, shard_folder, write_png
-from .shard import agreed_weights, shard_by_size
+from .shard import agreed_weights, gz_text_bytes, shard_by_size
 
 
 # Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
@@ -76,10 +76,10 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     tm = timings if timings is not None else {}
     for key in ("stage_wait_s", "upload_s", "inflate_s", "kernels_s", "png_submit_s", "png_tail_s"):
         tm.setdefault(key, 0.0)
-    # batches by text size in HBM (gzip files count 6x their size on disk: they are inflated on the GPU)
+    # batches by text size in HBM (a gzip file counts the text its framing names, shard.gz_text_bytes: it is inflated on the GPU)
     batches, batch, nbytes = [], [], 0
     for f in todo:
-        sz = os.path.getsize(f) * (6 if f.suffix == ".gz" else 1)
+        sz = gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
         if batch and nbytes + sz > (min(batch_bytes, FIRST_BATCH_BYTES) if not batches else batch_bytes):
             batches.append((batch, nbytes))
             batch, nbytes = [], 0
@@ -193,7 +193,7 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
         batch, nbytes = [], 0
         t0 = time.perf_counter()
         for f in mine[i:]:
-            sz = os.path.getsize(f) * (6 if f.suffix == ".gz" else 1)
+            sz = gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
             if batch and nbytes + sz > batch_bytes:
                 break
             batch.append(f)

@@ -92,19 +92,63 @@ def rank_loads(weights, world):
     return [sum(int(weights[i]) for i in shard_by_size(weights, r, world)) for r in range(world)]
 
 
-GZ_TEXT_RATIO = 6   # text bytes per compressed byte assumed when plain and gzip files meet in one job (pipeline's batching uses the same)
+GZ_TEXT_RATIO = 6   # text bytes per compressed byte assumed for a gzip file that does not say (see gz_text_bytes)
+
+
+def gz_text_bytes(path, size=None):
+    """Text bytes of a gzip file without inflating it -- what its own framing says, read from a few dozen bytes:
+      * one member (what split_fastq / pigz / gzip write): the ISIZE word that ends the file, + 2^32 as often as it takes
+        to reach the file's own size (ISIZE is the text size modulo 2^32, and FASTQ text is never smaller than its gzip);
+      * BGZF (bgzip, BBTools through bgzip; the `BC` extra field): members of at most 64 KiB of text each, the last an
+        empty end marker whose ISIZE is 0 -- the text-to-file ratio of the FIRST block (its ISIZE over its BSIZE)
+        times the file size (the engine walks every block header when it stages the file; a weight needs no more);
+      * anything else (several members glued together, a size word below the file size that is no wrap): the file
+        size times GZ_TEXT_RATIO, the rule of round 5.
+    Never raises: an unreadable file weighs its size times GZ_TEXT_RATIO (it fails later, on the rank that gets it)."""
+    try:
+        if size is None:
+            size = os.path.getsize(path)
+        if size < 18:
+            return 0
+        with open(path, "rb") as f:
+            head = f.read(18)
+            if head[:2] != b"\x1f\x8b":
+                return size                                   # not gzip after all: plain text under a .gz name
+            if head[3] & 4 and head[12:14] == b"BC" and int.from_bytes(head[10:12], "little") >= 6:
+                bsize = int.from_bytes(head[16:18], "little") + 1
+                if 26 <= bsize <= size:
+                    f.seek(bsize - 4)
+                    isize = int.from_bytes(f.read(4), "little")
+                    if 0 < isize <= 65536:
+                        return int(size * (isize / bsize))
+                return size * GZ_TEXT_RATIO
+            f.seek(size - 4)
+            isize = int.from_bytes(f.read(4), "little")
+        if isize >= size // 2:          # one member whose size word is plausible for text (ratio >= 0.5)
+            return isize
+        if size >= (1 << 31):           # a wrap: text of 4 GiB and more
+            est = isize
+            while est < size:
+                est += 1 << 32
+            return est
+        return size * GZ_TEXT_RATIO      # several members glued together: the last one's size says nothing
+    except OSError:
+        try:
+            return (size if size is not None else os.path.getsize(path)) * GZ_TEXT_RATIO
+        except OSError:
+            return 0
 
 
 def file_weights(files):
-    """Work estimate of each input file: its text bytes (a .gz counts GZ_TEXT_RATIO times its size; a
-    missing file 0 -- it fails later, on the rank that gets it)."""
+    """Work estimate of each input file: its text bytes (a .gz: gz_text_bytes; a missing file 0 -- it fails later, on
+    the rank that gets it)."""
     out = []
     for f in files:
         try:
             sz = os.path.getsize(f)
         except OSError:
             sz = 0
-        out.append(sz * (GZ_TEXT_RATIO if str(f).endswith(".gz") else 1))
+        out.append(gz_text_bytes(f, sz) if str(f).endswith(".gz") and sz else sz)
     return out
 
 

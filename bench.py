@@ -225,7 +225,9 @@ def end_to_end(eng, args):
         nfiles //= 2
     from varkoder_amd.engine import plain_route
     out = {"files": nfiles, "files_asked": args.e2e_files, "reads_per_file": reads, "read_len": args.readlen,
-           "io_threads": threads, "plain_text_route": plain_route(threads)}
+           "io_threads": threads, "plain_text_route": plain_route(threads, eng) + " at the start (a run that waits for its staging "
+                                                      "threads goes over to the mapped route: where_the_median_pass_went_s."
+                                                      "plain_route_switched_at_batch)"}
     try:
         # generated on the device in slabs of 32 files and copied back (a 46 GB tensor at once would also do,
         # but the pool of the main measurement is still resident)
@@ -462,18 +464,23 @@ def ladder_shard(eng, args, rank, world, dist, red_dev):
     reads = [max(1, int(n.split("@")[1][:8]) * 1000 // args.readlen) for n in names]
     rec = 2 * args.readlen + 20
     weights = [r * rec for r in reads]
-    mine = shard.shard_by_size(weights, rank, world)
-    loads = shard.rank_loads(weights, world)
+    # as pipeline.fastqs_to_images deals files: the head of the longest-first order statically, the last tenth of the weight
+    # pulled from a shared cursor by whichever rank is free (every rank keeps the tail's units in HBM: a tenth of the bytes)
+    head, tail = shard.split_head_tail(weights, 0.1)
+    mine = [head[j] for j in shard.shard_by_size([weights[i] for i in head], rank, world)]
+    chunk = max(1, len(tail) // (6 * world))
+    static_loads = shard.rank_loads(weights, world)
     rr = [sum(weights[i] for i in shard.shard_indices(len(names), r, world)) for r in range(world)]
-    err, per_pass = None, []
+    err, per_pass, took_bytes = None, [], []
     try:
-        offs = np.zeros(len(mine), dtype=np.uint64)
-        lens = np.array([weights[i] for i in mine], dtype=np.uint64)
-        if len(mine) > 1:
+        units = mine + tail
+        offs = np.zeros(len(units), dtype=np.uint64)
+        lens = np.array([weights[i] for i in units], dtype=np.uint64)
+        if len(units) > 1:
             offs[1:] = np.cumsum((lens[:-1] + np.uint64(15)) // np.uint64(16) * np.uint64(16))
-        total = int(offs[-1] + lens[-1]) if len(mine) else 0
+        total = int(offs[-1] + lens[-1]) if len(units) else 0
         buf = torch.empty(((total + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=eng.device)
-        for j, i in enumerate(mine):   # unit i is "sample" (3 << 20) + i of the generator: the same text whoever gets it
+        for j, i in enumerate(units):   # unit i is "sample" (3 << 20) + i of the generator: the same text whoever gets it
             eng.synth((3 << 20) + i, 1, reads[i], args.readlen, dist=args.dist, out=buf[int(offs[j]):])
         img, hist, status = eng.fastq_to_images(buf, offs, lens)     # warm-up: workspaces
         torch.cuda.synchronize()
@@ -484,30 +491,49 @@ def ladder_shard(eng, args, rank, world, dist, red_dev):
     if flag.item() < 0.5:
         return {"error": err or "another rank failed while making its units"}
     bad = 0
+    nh = len(mine)
     for rep in range(3):
+        queue = shard.TailQueue(len(tail))    # (every rank, in the same order: the cursor's key is a sequence number)
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        nbytes = 0
         try:   # (a rank that fails here still takes part in the pass's collectives: its time reads NaN)
-            img, hist, status = eng.fastq_to_images(buf, offs, lens)
+            if nh:
+                img, hist, status = eng.fastq_to_images(buf, offs[:nh], lens[:nh])
+                bad = int((status != 0).sum().item())       # (the copy back is the launch's synchronisation point)
+                nbytes += int(lens[:nh].sum())
+            while True:
+                got = queue.next(chunk)
+                if len(got) == 0:
+                    break
+                sel = np.array([nh + j for j in got])
+                img, hist, status = eng.fastq_to_images(buf, offs[sel], lens[sel])
+                bad += int((status != 0).sum().item())
+                nbytes += int(lens[sel].sum())
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            bad = int((status != 0).sum().item())
         except Exception as e:  # noqa: BLE001
             err, dt = repr(e), float("nan")
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([dt, float(nbytes)], dtype=torch.float64, device=red_dev)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
-        per_pass.append([float(x.item()) * 1e3 for x in every])
+        per_pass.append([float(x[0].item()) * 1e3 for x in every])
+        took_bytes.append([int(x[1].item()) for x in every])
     if any(x != x for p in per_pass for x in p):
         return {"error": err or "another rank failed in a timed pass", "ms_by_rank_all_passes": per_pass}
     worst = [max(p) for p in per_pass]
     mid = sorted(range(len(worst)), key=lambda i: worst[i])[len(worst) // 2]
-    mean = sum(loads) / world
-    return {"units": len(names), "samples": ns, "rungs_kbp": rungs_kbp, "rule": "shard.shard_by_size (longest first, least-loaded rank)",
-            "bytes_by_rank": loads, "max_over_mean_bytes": max(loads) / mean,
-            "ms_by_rank_median_pass": per_pass[mid], "ms_by_rank_all_passes": per_pass,
+    mean = sum(weights) / world
+    ms = per_pass[mid]
+    return {"units": len(names), "samples": ns, "rungs_kbp": rungs_kbp,
+            "rule": "shard.split_head_tail + shard_by_size + TailQueue (longest first to the least-loaded rank; the last tenth of the "
+                    "bytes pulled from a shared cursor, %d units a claim)" % chunk,
+            "head_units": len(head), "tail_units": len(tail),
+            "bytes_by_rank": took_bytes[mid], "max_over_mean_bytes": max(took_bytes[mid]) / mean,
+            "ms_by_rank_median_pass": ms, "max_over_mean_ms": max(ms) / (sum(ms) / world), "ms_by_rank_all_passes": per_pass,
             "gbases_per_s": sum(r * args.readlen for r in reads) / (worst[mid] * 1e-3) / 1e9,
+            "static_deal_bytes_by_rank": static_loads, "static_deal_max_over_mean_bytes": max(static_loads) / mean,
             "round_robin_bytes_by_rank": rr, "round_robin_max_over_mean_bytes": max(rr) / mean,
             "bad_status_units_this_rank": bad}
 

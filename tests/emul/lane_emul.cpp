@@ -279,7 +279,7 @@ int count_dense_impl(const uint8_t* s, uint64_t len, uint32_t parts, uint32_t* h
                         lphs[lane] = (pph + excl) & 3u;
                         excl += c;
                         uint32_t s_raw;
-                        plainl[lane] = vkl::seq_span_note(mlo, mhi, c, lphs[lane], sp[lane], ep[lane], s_raw);
+                        plainl[lane] = vkl::seq_span_note(mlo, mhi, c, (1u - lphs[lane]) & 3u, sp[lane], ep[lane], s_raw);
                         na += plainl[lane] ? 0u : 1u;
                     }
                     total = excl;

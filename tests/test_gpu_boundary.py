@@ -344,7 +344,10 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert all(len(p) == 2 for p in e["passes_s_by_rank"]) and len(e["passes_s_by_rank"]) == 3
     ls = d["ladder_shard"]                                # units of unequal size (the reference's six-rung ladder), sharded by size
     assert ls["units"] == 12 and len(ls["bytes_by_rank"]) == 2 and len(ls["ms_by_rank_median_pass"]) == 2
-    assert ls["max_over_mean_bytes"] <= 1.05 < ls["round_robin_max_over_mean_bytes"] and ls["bad_status_units_this_rank"] == 0
+    assert ls["static_deal_max_over_mean_bytes"] <= 1.05 < ls["round_robin_max_over_mean_bytes"] and ls["bad_status_units_this_rank"] == 0
+    # round 6: the last tenth of the bytes is pulled from a shared cursor by whichever rank is free -- every unit still once
+    assert ls["head_units"] + ls["tail_units"] == 12 and ls["tail_units"] >= 1
+    assert sum(ls["bytes_by_rank"]) == sum(ls["static_deal_bytes_by_rank"]) and ls["max_over_mean_ms"] >= 1.0
     # a launcher that disagrees with --gpus is an error, not a silent one-rank run
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                          capture_output=True, text=True, timeout=300, cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"))

@@ -321,3 +321,36 @@ def test_bgzf_table_refuses_blocks_that_claim_more_than_64k_of_text():
     assert m is not None and int(m[2].sum()) == 15
     hostile = block(b"@r\nACGT\n+\nIIII\n", isize=0xFFFFFF00) + block(b"")
     assert bgzf_members(np.frombuffer(hostile, dtype=np.uint8)) is None
+
+
+def test_route_chooser_tries_the_other_route_when_the_first_runs_under_the_link_rate():
+    """pipeline.RouteChooser: batches 1-3 on the first route; under 85 % of the link's rate the other route gets its batches,
+    and the faster one keeps the rest -- a host whose read() into pinned memory holds the copies back ends up on the
+    mapped route by measurement, a fast one never leaves the staged route."""
+    import numpy as np
+    from varkoder_amd import pipeline
+
+    class FakeEngine:
+        route_override = None
+
+        def h2d_link_rate(self):
+            return 50e9
+
+    def staged(route):
+        return {"disk": np.array([2_000_000_000, 1000], dtype=np.uint64), "is_gz": np.array([False, True]), "plain_route": route}
+
+    def run(rates):
+        eng, tm = FakeEngine(), {}
+        ch = pipeline.RouteChooser(eng, tm)
+        seen = []
+        for bi in range(12):
+            route = eng.route_override or "staged"
+            seen.append(route)
+            ch.batch_done(bi, staged(route), 2e9 / rates[route])
+        return seen, tm
+    seen, tm = run({"staged": 40e9, "mapped": 48e9})
+    assert seen[:4] == ["staged"] * 4 and seen[-1] == "mapped" and tm["plain_route_rates_gb_s"]["chosen"] == "mapped"
+    seen, tm = run({"staged": 40e9, "mapped": 30e9})
+    assert seen[-1] == "staged" and "mapped" in seen and tm["plain_route_rates_gb_s"]["chosen"] == "staged"
+    seen, tm = run({"staged": 48e9, "mapped": 10e9})
+    assert set(seen) == {"staged"} and "chosen" not in tm["plain_route_rates_gb_s"]

@@ -255,6 +255,67 @@ def test_ranks_that_see_different_sizes_still_partition_the_files(tmp_path):
     assert sorted(mine0 + mine1) == list(range(5))   # every file exactly once
 
 
+def _tail_worker(rank, world, port, weights, cost, scale, out):
+    """One rank of a job whose items cost `cost` seconds (x scale) -- which the scheduler does NOT know: it deals by `weights`."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    from varkoder_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    head, tail = shard.split_head_tail(weights, 0.1)
+    mine = [head[j] for j in shard.shard_by_size([weights[i] for i in head], rank, world)]
+    queue = shard.TailQueue(len(tail))
+    chunk = max(1, len(tail) // (6 * world))
+    dist.barrier()
+    took = []
+    for i in mine:
+        time.sleep(cost[i] * scale)
+        took.append(i)
+    while True:
+        got = queue.next(chunk)
+        if len(got) == 0:
+            break
+        for j in got:
+            time.sleep(cost[tail[j]] * scale)
+            took.append(tail[j])
+    out.put((rank, took))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_the_tail_queue_balances_what_the_weights_got_wrong(world):
+    """Mixed inputs: plain files, gzip files whose inflate makes a text byte dearer, k = 9 samples whose count time depends on
+    their bases -- the weights (text bytes) are off by up to 30 % per item, in a way that lines up with the deal (the dearer
+    kind sorts together).  Dealt statically, the ranks' real time differs by more than the bound; with the last tenth of
+    the weight pulled from the shared cursor by whoever is free, max / mean of the MODELLED time (the sum of the real
+    costs of what a rank processed) is within 5 %."""
+    from varkoder_amd import shard
+    rng = np.random.default_rng(world)
+    n = 40 * world
+    weights = [int(w) for w in rng.integers(50, 400, size=n // 2)] + [int(w) for w in rng.integers(2, 30, size=n - n // 2)]
+    kind = rng.integers(0, 3, size=n)                       # 0 plain, 1 gzip, 2 k = 9 on skewed bases
+    factor = np.array([1.0, 1.3, 1.15])[kind]
+    cost = [float(w * f) for w, f in zip(weights, factor)]
+    # static deal alone, for the record: its imbalance in real cost
+    static = [sum(cost[i] for i in shard.shard_by_size(weights, r, world)) for r in range(world)]
+    scale = 2.0 / (sum(cost) / world)                       # ~2 s of sleeping per rank
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tail_worker, args=(r, world, port, weights, cost, scale, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(out.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(i for took in got.values() for i in took) == list(range(n))      # every item exactly once
+    modelled = [sum(cost[i] for i in got[r]) for r in range(world)]
+    assert max(modelled) / (sum(modelled) / world) <= 1.05, (modelled, static)
+
+
 def _giant_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import torch

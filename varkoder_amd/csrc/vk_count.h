@@ -1384,12 +1384,12 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 const uint32_t c = vkl::popc(mlo) + vkl::popc(mhi);
                 const uint32_t incl = wave_inclusive_sum(c);
                 total = lane_bcast(incl, 63);
-                const uint32_t lph = (pph + incl - c) & 3u;
+                const uint32_t dn = (c - incl + (1u - pph)) & 3u;   // line ends to pass before a sequence line starts: (1 - line phase) & 3
                 uint32_t s_raw;
                 // (one note per lane: a stretch that starts inside a granule AND ends in this lane -- a read under 64 bases --
                 // is set aside like the shapes seq_span itself refuses)
-                const bool plain = vkl::seq_span_note(mlo, mhi, c, lph, s, e, s_raw);
-                const unsigned long long am = __ballot(!plain);
+                const bool plain = vkl::seq_span_note(mlo, mhi, c, dn, s, e, s_raw);
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(!plain);   // (the compare's own lane mask: __ballot() makes a 0 / 1 of it and compares again)
                 if (am != 0ull) {   // rare: lanes set aside (see above), or too many of them
                     const uint32_t na = static_cast<uint32_t>(__builtin_popcountll(am));
 #ifdef VK_DIAG_NO_ASIDE   // diagnostic build: every such piece down the general path, as before round 4
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                             // (a buffer store: with a 64-bit address in registers the branch spilled two register pairs and
                             // waited for them -- and for this store -- with vmcnt(0): 6 % of wave time on fastp-shaped reads)
                             const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(alist, 0, static_cast<int>(aside_cap * 4u), 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b32(((it * 64u + ln) << 3) | (before ? 4u : 0u) | lph, arsrc, (naside + below) * 4u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(((it * 64u + ln) << 3) | (before ? 4u : 0u) | ((1u - dn) & 3u), arsrc, (naside + below) * 4u, 0, 0);
                             // the separator: the lane's first granule as it is, under the note "the line ends at position 0" --
                             // no sequence bytes, whatever the bytes are (until round 6 the granule was overwritten with
                             // newlines: a write to the piece's registers in a branch, four moves on every piece's way)
@@ -1475,25 +1475,29 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 const uint32_t mine0 = npend + incl - n;   // place in the stream (64 per round) of this lane's first granule
                 const uint32_t first = mine0 - gs;         // + g = the place of its granule g
                 // round and buffer address of every granule of this lane (round kNoRound: none of its rounds)
-                constexpr uint32_t kNoRound = 0x03FFFFFFu;
+                constexpr uint32_t kNoRound = 0xFFFFFFFFu;   // (an inline constant; so is the "no note" place below: -1 >> 6 is no round either)
                 const uint32_t xb_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint4*)xb));
                 uint32_t rd[5], ad[5];
-                uint32_t xbv;   // (the base in a vector register: v_lshl_add takes one scalar operand at most, and the shift is one)
-                asm("v_mov_b32 %0, %1" : "=v"(xbv) : "s"(xb_base));
+                // (granule g is this lane's iff bit g of ((1 << n) - 1) << gs is set: one v_bfm, then a sign-extended bit per
+                // slot -- all ones on a slot that is not -- instead of a subtraction, a comparison and a select each)
+                uint32_t minebits;
+                asm("v_bfm_b32 %0, %1, %2" : "=v"(minebits) : "v"(n), "v"(gs));   // ((1 << n) - 1) << gs; n, gs <= 4
 #pragma unroll
                 for (uint32_t g = 0; g < 4; ++g) {
                     const uint32_t place = first + g;
-                    rd[g] = (g - gs < n) ? place >> 6 : kNoRound;
-                    ad[g] = vkl::lshl_add(place & 63u, 4, xbv);
+                    uint32_t own;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(own) : "v"(minebits), "n"(g));   // all ones: this lane's
+                    rd[g] = (place >> 6) | ~own;    // kNoRound on a slot that is not this lane's
+                    ad[g] = vkl::lshl_add_s(place & 63u, 4, xb_base);
                 }
                 // The note of the stretch's edge granule (vk_lane.h, classify_granule_note) is set on the granule's copy in the
                 // buffer (the piece's registers stay as loaded: four aligned 128-bit tuples the stores can take as they are):
                 // where the first base is (s & 15 != 0), else where the line ends (e < 64); never both (span_one_note), so
                 // one of s & 15 and e & 15 is zero (a stretch that starts inside a granule runs on: e = 64).
                 const bool has_s = (s & 15u) != 0u;        // (s = 64: no)
-                const uint32_t pnote = has_s ? mine0 : (e < 64u ? mine0 + n - 1u : 0xFFFFFFC0u);
+                const uint32_t pnote = has_s ? mine0 : (e < 64u ? mine0 + n - 1u : 0xFFFFFFFFu);
                 rd[4] = pnote >> 6;
-                ad[4] = vkl::lshl_add(pnote & 63u, 4, xbv);
+                ad[4] = vkl::lshl_add_s(pnote & 63u, 4, xb_base);
                 const uint32_t note_lo = vkl::note_spread((s | e) & 15u), note_hi = has_s ? 0u : vkl::kGranuleEnd;
                 const uint32_t rounds = tot >> 6;
                 // put(r): the granules whose round is r go into the buffer, the note behind them.  Hand-written (the

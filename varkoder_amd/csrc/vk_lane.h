@@ -120,6 +120,17 @@ VKL_FN uint32_t lshl_or(uint32_t a, uint32_t sh, uint32_t c) {
 #endif
 }
 
+// (a << sh) + c with c wave-uniform (a scalar register: the one scalar operand a three-operand instruction may have)
+VKL_FN uint32_t lshl_add_s(uint32_t a, uint32_t sh, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(sh), "s"(c));
+    return d;
+#else
+    return (a << sh) + c;
+#endif
+}
+
 // (a << sh) + c as one instruction; sh must fold to a constant
 VKL_FN uint32_t lshl_add(uint32_t a, uint32_t sh, uint32_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -660,8 +671,9 @@ VKL_FN bool span_one_note(uint32_t s, uint32_t e) { return (s & 15u) == 0u || e 
 // granule rules (start and end in one granule; two line ends in front of a start) were the tag's limits and are
 // gone: the note names the position itself.  What stays: at most three newlines (two when two or three line ends
 // must pass first: the candidates stop at the second newline), and span_one_note.
-VKL_FN bool seq_span_note(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, uint32_t& s, uint32_t& e, uint32_t& s_raw) {
-    const uint32_t dn = (1u - lph) & 3u;
+// dn: the line ends to pass before a sequence line starts, (1 - line phase) & 3 (the caller has it one subtraction sooner
+// than the phase).
+VKL_FN bool seq_span_note(uint32_t lo, uint32_t hi, uint32_t c, uint32_t dn, uint32_t& s, uint32_t& e, uint32_t& s_raw) {
     const uint32_t p1 = first_bit64(lo, hi);
     const uint32_t lo1 = lo & (lo - 1u), hi1 = lo ? hi : (hi & (hi - 1u));
     const uint32_t p2 = first_bit64(lo1, hi1);
@@ -670,7 +682,8 @@ VKL_FN bool seq_span_note(uint32_t lo, uint32_t hi, uint32_t c, uint32_t lph, ui
     s_raw = (pr + 1u) & 0xFFu;
     s = umin(s_raw, 64u);
     e = (pr >> 8) & 0xFFu;
-    return c <= (dn >= 2u ? 2u : 3u) && span_one_note(s, e);
+    // c <= (dn >= 2 ? 2 : 3), as one comparison: 2 c + dn <= 7
+    return 2u * c + dn <= 7u && span_one_note(s, e);
 }
 
 // Heavy stage, one all-ASCII granule with its note: codes (2-bit geometry) and BAD -- not a base of the sequence
@@ -701,7 +714,15 @@ VKL_FN void classify_granule_note(uint32_t a0, uint32_t a1, uint32_t a2, uint32_
 #else
     const uint32_t S = static_cast<uint32_t>(static_cast<int32_t>(a1 << 24) >> 31);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    // positions from p on: ~0 << 2p, the shift count being byte 1 of m (one SDWA shift instead of a shift and a shift).  By
+    // hand, so the wait states a v_dot4 result needs in front of its reader are written out (tools/asm_lint.py: DOT, 3).
+    uint32_t X;
+    asm("s_nop 2\n\tv_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+        : "=v"(X) : "v"(m), "v"(0xFFFFFFFFu));
+#else
     const uint32_t X = 0xFFFFFFFFu << ((m >> 8) & 31u);                  // positions from p on
+#endif
     Cout = C;
     SEQout = X ^ S;
     BADout = IV | ~(X ^ S);

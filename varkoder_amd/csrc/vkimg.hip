@@ -445,12 +445,12 @@ uint32_t choose_parts(uint32_t nsamples, uint64_t maxlen, int k) {
         // "rounds" of the chip in lock-step -- and the wave-cycle counter read 85 % of the launch (profiles/r05a): a
         // workgroup's slot is held until its slowest wavefront is through its sixteenth of the sample, and a CU that runs
         // a few per cent behind (another XCD's L2, a busier memory channel) ends the launch alone.  In workgroups of
-        // 10-27 MB the dispatcher hands the faster CUs more of them: 65.6 -> 62.6 ms for 1000 samples, 7.13 -> 6.63 for 100,
+        // 10-27 MB (20 MiB is the rule) the dispatcher hands the faster CUs more of them: 65.6 -> 62.6 ms for 1000 samples, 7.13 -> 6.63 for 100,
         // 74.1 -> 71.1 on fastp-shaped reads (profiles/ab/r06_parts.txt; flat from 12 to 32 parts, slower again from 64:
         // every workgroup zeroes and flushes a 64 KB histogram and every wavefront finds its line phase).  At least four
         // rounds of the chip where that leaves workgroups of 4 MiB.
         const uint64_t cap4 = maxlen / (4ull << 20) > 1 ? maxlen / (4ull << 20) : 1;
-        uint64_t parts = (maxlen + (8ull << 20)) / (16ull << 20);
+        uint64_t parts = (maxlen + (10ull << 20)) / (20ull << 20);
         if (parts < 1) parts = 1;
         const uint64_t want = (4 * kSlots + nsamples - 1) / nsamples;
         if (parts < want) parts = want < cap4 ? want : cap4;

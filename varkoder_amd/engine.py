@@ -73,9 +73,16 @@ USE_MAPPED_UPLOAD = {"1": True, "0": False}.get(os.environ.get("VARKODER_AMD_MMA
 MAPPED_BELOW_THREADS = 16
 
 
-def plain_route(threads):
-    """"mapped" or "staged": how stage_files brings plain-text files in for a rank with this many I/O threads."""
-    return "mapped" if (USE_MAPPED_UPLOAD if USE_MAPPED_UPLOAD is not None else threads < MAPPED_BELOW_THREADS) else "staged"
+def plain_route(threads, engine=None):
+    """"mapped" or "staged": how stage_files brings plain-text files in for a rank with this many I/O threads.
+    VARKODER_AMD_MMAP decides when set; else what the engine's pipeline has switched to (ImageEngine.route_override:
+    pipeline.fastqs_to_images goes over to the mapped route when its staging threads -- read() into pinned memory -- keep
+    the copy engine waiting); else mapped below MAPPED_BELOW_THREADS threads."""
+    if USE_MAPPED_UPLOAD is not None:
+        return "mapped" if USE_MAPPED_UPLOAD else "staged"
+    if engine is not None and getattr(engine, "route_override", None) in ("mapped", "staged"):
+        return engine.route_override
+    return "mapped" if threads < MAPPED_BELOW_THREADS else "staged"
 
 
 class ImageEngine:
@@ -93,6 +100,7 @@ class ImageEngine:
             raise _capi.VkError(_capi.VK_EHIP, "no GPU visible: the HIP path cannot run (no CPU fallback)")
         self.k = k
         self.mapping = mapping
+        self.route_override = None   # see plain_route
         self.device = torch.device("cuda", device)
         self.L = _capi.lib()
         torch.cuda.set_device(self.device)
@@ -170,6 +178,25 @@ class ImageEngine:
         torch.cuda.current_stream(self.device).synchronize()   # the staging buffer is reused
         return dev, offs, lens
 
+    def h2d_link_rate(self):
+        """Bytes per second of a pinned -> device copy on this engine's device (128 MiB, best of three; measured once)."""
+        if getattr(self, "_h2d_rate", None) is None:
+            import time
+            torch = _torch()
+            n = 128 << 20
+            src = torch.empty(n, dtype=torch.uint8).pin_memory()
+            dst = torch.empty(n, dtype=torch.uint8, device=self.device)
+            best = 0.0
+            for _ in range(3):
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                dst.copy_(src, non_blocking=True)
+                torch.cuda.synchronize(self.device)
+                best = max(best, n / (time.perf_counter() - t0))
+            self._h2d_rate = best
+            del src, dst
+        return self._h2d_rate
+
     def stage_files(self, paths, pool=None, slot=0):
         """Host half of upload_files: read the files, AS THEY ARE ON DISK, into pinned staging buffer
         `slot` (kept and grown across calls) with parallel readinto, no intermediate copy.  Plain FASTQ
@@ -234,7 +261,7 @@ class ImageEngine:
         # input, not the 57 GB/s link.  A file that cannot be mapped goes through the buffer as before.
         mapped = {}
         threads = getattr(pool, "_max_workers", 1) if pool is not None else 1
-        if plain_route(threads) == "mapped":
+        if plain_route(threads, self) == "mapped":
             def map_file(i):
                 if int(disk[i]) == 0:
                     return None
@@ -312,7 +339,8 @@ class ImageEngine:
         text_total = pos + 16
         return {"pinned": pinned, "plain_total": plain_total, "stage_total": stage_total, "text_total": text_total,
                 "is_gz": is_gz, "src": src, "disk": disk, "offs": offs, "lens": lens, "caps": caps,
-                "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped, "unreadable": unreadable}
+                "paths": [str(p) for p in paths], "bgzf": bgzf, "mapped": mapped, "unreadable": unreadable,
+                "plain_route": "mapped" if any(not is_gz[i] for i in mapped) else "staged"}
 
     def _release_mapped(self, mapped, which=None):
         """Unpin and unmap files of a batch (all, or those named) -- on a helper thread: it is a few milliseconds per

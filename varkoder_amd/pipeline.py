@@ -14,7 +14,7 @@ from pathlib import Path
 
 from .config import QUAL_THRESH
 from .image import counts_name, eprint, png_name, shard_folder, write_png
-from .shard import agreed_weights, gz_text_bytes, shard_by_size
+from .shard import TailQueue, agreed_weights, gz_text_bytes, shard_by_size, split_head_tail
 
 
 # Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
@@ -31,9 +31,59 @@ def image_name(fastq_path, k, mapping_code):
     return png_name(counts_name(fastq_path, k), mapping_code)
 
 
+class RouteChooser:
+    """Plain-text files reach HBM by one of two routes (engine.plain_route): STAGED -- the I/O threads read() them into a
+    pinned buffer, one DMA per batch -- or MAPPED -- the files' page-cache pages are mapped and the GPU copies out of
+    them, no read() at all.  Which is faster depends on the host: with 16 fast cores the staged route runs at the link's
+    rate (BENCH_r04: 56 of 57.6 GB/s); on a slower host the read() copies -- and the memory bandwidth they take from the DMA
+    -- hold it at 44 (BENCH_r05).  So the run measures itself: batches 1-3 on the route it starts with; if they moved
+    less than 85 % of what the link carries (measured once, 128 MiB pinned -> device), batches 5-7 on the other route,
+    and the rest on whichever was faster.  VARKODER_AMD_MMAP=0/1 pins the route and switches this off."""
+
+    def __init__(self, eng, tm):
+        from . import engine as E
+        self.eng, self.tm, self.E = eng, tm, E
+        self.on = E.USE_MAPPED_UPLOAD is None and getattr(eng, "route_override", None) is None and hasattr(eng, "h2d_link_rate")
+        self.rate = {}          # route -> [plain bytes, seconds] over the batches that count
+        self.first = None       # the route the run began on
+        self.trial_from = None  # batch at which the other route's trial began
+
+    def batch_done(self, bi, staged, seconds):
+        if not self.on or bi == 0:   # (the first batch is a short one)
+            return
+        if not isinstance(staged, dict) or "disk" not in staged:
+            return
+        plain = int(staged["disk"][~staged["is_gz"]].sum()) if len(staged["disk"]) else 0
+        if plain == 0:
+            return
+        route = staged.get("plain_route", "staged")   # (as stage_files brought this batch in)
+        acc = self.rate.setdefault(route, [0, 0.0])
+        acc[0] += plain
+        acc[1] += seconds
+        if self.first is None:
+            self.first = route
+        other = "staged" if self.first == "mapped" else "mapped"
+        if self.trial_from is None:
+            if bi >= 3 and route == self.first:
+                link = self.eng.h2d_link_rate()
+                got = acc[0] / acc[1]
+                self.tm["plain_route_rates_gb_s"] = {route: got / 1e9, "link": link / 1e9}
+                if got < 0.85 * link:
+                    self.eng.route_override = other
+                    self.trial_from = bi
+                else:
+                    self.on = False
+        elif other in self.rate and bi >= self.trial_from + 4:   # (the batch staged before the switch went the old way)
+            a, b = self.rate[self.first], self.rate[other]
+            best = other if b[0] / b[1] > a[0] / a[1] else self.first
+            self.eng.route_override = best
+            self.tm["plain_route_rates_gb_s"].update({other: b[0] / b[1] / 1e9, "chosen": best})
+            self.on = False
+
+
 def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_sd=None, overwrite=False,
                      subfolder_levels=0, device=0, rank=0, world=1, batch_bytes=None, io_threads=8,
-                     engine=None, verbose=False, timings=None, weights=None):
+                     engine=None, verbose=False, timings=None, weights=None, tail_frac=0.1):
     """Process this rank's share of `files`.  Returns {sample_file_stem: OrderedDict(stats)}
     with the reference's stats keys `<k>mer_counting_time` and `k<k>_img_time` (per-file
     share of the batch wall time) or `failed_step` for files whose FASTQ framing is bad.
@@ -50,7 +100,18 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     base_sd = base_sd or {}
     if weights is None:
         weights = agreed_weights(files)
-    mine = [files[i] for i in shard_by_size(weights, rank, world)]   # size-aware; rank 0's view of the sizes: see shard.agreed_weights
+    # Size-aware (rank 0's view of the sizes: shard.agreed_weights).  With a process group, the longest files -- nine tenths
+    # of the weight -- are dealt statically, and the many small ones at the end of the order are pulled from a shared
+    # cursor by whichever rank gets there first (shard.split_head_tail, TailQueue): the deal balances estimates, the
+    # tail what they got wrong.  (The queue is made here, before anything a single rank could fail in: every rank
+    # constructs it, none has to reach it.)
+    import torch.distributed as dist
+    grouped = world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == world
+    head, tail = split_head_tail(weights, tail_frac if grouped else 0.0)
+    mine = [files[head[j]] for j in shard_by_size([weights[i] for i in head], rank, world)]
+    tail_files = [files[i] for i in tail]
+    tail_queue = TailQueue(len(tail_files)) if tail_files else None
+    tail_chunk = max(1, len(tail_files) // (6 * world))   # files per claim: ~6 claims per rank
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
     outdir.mkdir(parents=True, exist_ok=True)
@@ -62,44 +123,69 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         name = image_name(f, k, mapping_code)
         return shard_folder(outdir, name, subfolder_levels), name
 
-    todo = []
-    for f in mine:
-        d, name = target(f)
-        if not overwrite and (d / name).is_file():
-            eprint("File exists. Skipping image for file:", str(f))
-            continue
-        todo.append(f)
+    def wanted(fs):
+        out = []
+        for f in fs:
+            d, name = target(f)
+            if not overwrite and (d / name).is_file():
+                eprint("File exists. Skipping image for file:", str(f))
+                continue
+            out.append(f)
+        return out
 
+    todo = wanted(mine)
     import os
     if batch_bytes is None:
-        batch_bytes = DEFAULT_GZ_BATCH_BYTES if todo and all(f.suffix == ".gz" for f in todo) else DEFAULT_BATCH_BYTES
+        every = todo + tail_files
+        batch_bytes = DEFAULT_GZ_BATCH_BYTES if every and all(f.suffix == ".gz" for f in every) else DEFAULT_BATCH_BYTES
     tm = timings if timings is not None else {}
     for key in ("stage_wait_s", "upload_s", "inflate_s", "kernels_s", "png_submit_s", "png_tail_s"):
         tm.setdefault(key, 0.0)
-    # batches by text size in HBM (a gzip file counts the text its framing names, shard.gz_text_bytes: it is inflated on the GPU)
-    batches, batch, nbytes = [], [], 0
-    for f in todo:
-        sz = gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
-        if batch and nbytes + sz > (min(batch_bytes, FIRST_BATCH_BYTES) if not batches else batch_bytes):
-            batches.append((batch, nbytes))
-            batch, nbytes = [], 0
-        batch.append(f)
-        nbytes += sz
-    if batch:
-        batches.append((batch, nbytes))
+
+    def text_bytes(f):
+        return gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
+
+    def batch_source():
+        """This rank's batches, by text size in HBM (a gzip file counts the text its framing names, shard.gz_text_bytes: it is
+        inflated on the GPU): its static share first, then what it claims of the tail, a chunk per batch."""
+        batch, nbytes, first = [], 0, True
+        for f in todo:
+            sz = text_bytes(f)
+            if batch and nbytes + sz > (min(batch_bytes, FIRST_BATCH_BYTES) if first else batch_bytes):
+                yield batch, nbytes
+                batch, nbytes, first = [], 0, False
+            batch.append(f)
+            nbytes += sz
+        if batch:
+            yield batch, nbytes
+        while tail_queue is not None:
+            got = tail_queue.next(tail_chunk)
+            if len(got) == 0:
+                break
+            batch = wanted([tail_files[i] for i in got])
+            tm["tail_files"] = tm.get("tail_files", 0) + len(batch)
+            if batch:
+                yield batch, sum(text_bytes(f) for f in batch)
     # The host half of a batch (file reads into a pinned buffer) runs one batch ahead on its own
     # thread, into the other of two staging buffers, while this thread copies and processes.
     stager = ThreadPoolExecutor(1)
     finisher, handed = ThreadPoolExecutor(1), []
     done = False
+    chooser = RouteChooser(eng, tm)
     try:
-        staged = stager.submit(eng.stage_files, batches[0][0], pool, 0) if batches else None
-        for bi, (batch, nbytes) in enumerate(batches):
+        source = batch_source()
+        cur = next(source, None)
+        staged = stager.submit(eng.stage_files, cur[0], pool, 0) if cur else None
+        bi = -1
+        while cur is not None:
+            bi += 1
+            batch, nbytes = cur
             t0 = time.perf_counter()
             ready = staged.result()
             tm["stage_wait_s"] += time.perf_counter() - t0
-            if bi + 1 < len(batches):
-                staged = stager.submit(eng.stage_files, batches[bi + 1][0], pool, (bi + 1) & 1)
+            cur = next(source, None)          # (a chunk of the tail is claimed here: one batch ahead, like the staging)
+            if cur is not None:
+                staged = stager.submit(eng.stage_files, cur[0], pool, (bi + 1) & 1)
             for h in handed:   # a hand-over that failed (a folder that cannot be made) stops the pass here, not after the last batch
                 if h.done() and h.exception() is not None:
                     raise h.exception()
@@ -113,6 +199,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
             nz = (hist != 0).any(dim=1).cpu().numpy()
             t2 = time.perf_counter()
             tm["kernels_s"] += t2 - t1
+            chooser.batch_done(bi, ready, t2 - t0)
 
             def hand_over(batch=batch, st=st, imgs=imgs, nz=nz, per_file=(t2 - t0) / len(batch)):
                 # stats rows and PNG jobs of one batch: on a thread of its own (batches in order), beside the next batch's
@@ -153,7 +240,7 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
         if not done and engine is None:
             eng.close()
     tm["png_tail_s"] += time.perf_counter() - tt
-    tm["batches"] = tm.get("batches", 0) + len(batches)
+    tm["batches"] = tm.get("batches", 0) + bi + 1
     if engine is None:
         eng.close()
     return stats

@@ -87,6 +87,53 @@ def shard_by_size(weights, rank, world):
     return sorted(mine)
 
 
+def split_head_tail(weights, tail_frac=0.1):
+    """(head, tail): the items in longest-first order (ties: lower index), cut where the weight still to come drops to
+    `tail_frac` of the total.  The head is dealt statically (shard_by_size over the head's weights); the tail -- the many
+    small items at the end of the order -- is what ranks that finish early pull from a shared counter (TailQueue), the
+    way the reference's pool hands the next sample to whichever worker is free (`imap_unordered`,
+    commands/image.py:1281-1284): a static deal balances ESTIMATES (a .gz's text bytes, a k = 9 count whose time
+    depends on the bases), the tail absorbs what the estimates got wrong."""
+    order = sorted(range(len(weights)), key=lambda i: (-int(weights[i]), i))
+    total = sum(int(w) for w in weights)
+    left, cut = total, len(order)
+    for n, i in enumerate(order):
+        if left <= tail_frac * total:
+            cut = n
+            break
+        left -= int(weights[i])
+    return order[:cut], order[cut:]
+
+
+class TailQueue:
+    """A shared cursor over `n` items for the ranks of the default process group: next(count) claims the next `count`
+    of them atomically (range, possibly empty at the end).  Control plane only: one counter in the group's own
+    key-value store (the TCPStore torchrun's rendezvous set up) -- no tensor, no data-path collective.  Every rank must
+    construct its queues in the same order (the key is a per-process sequence number).  Without a process group: a
+    local cursor."""
+    _seq = 0
+
+    def __init__(self, n):
+        import torch.distributed as dist
+        TailQueue._seq += 1
+        self.n = int(n)
+        self.key = "varkoder_amd_tail_%d" % TailQueue._seq
+        self.store = None
+        self.local = 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d
+            self.store = distributed_c10d._get_default_store()
+
+    def next(self, count=1):
+        count = max(1, int(count))
+        if self.store is None:
+            start = self.local
+            self.local += count
+        else:
+            start = int(self.store.add(self.key, count)) - count
+        return range(min(start, self.n), min(start + count, self.n))
+
+
 def rank_loads(weights, world):
     """Total weight of every rank under shard_by_size (tests, bench.py's report)."""
     return [sum(int(weights[i]) for i in shard_by_size(weights, r, world)) for r in range(world)]

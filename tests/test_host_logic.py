@@ -353,4 +353,4 @@ def test_route_chooser_tries_the_other_route_when_the_first_runs_under_the_link_
     seen, tm = run({"staged": 40e9, "mapped": 30e9})
     assert seen[-1] == "staged" and "mapped" in seen and tm["plain_route_rates_gb_s"]["chosen"] == "staged"
     seen, tm = run({"staged": 48e9, "mapped": 10e9})
-    assert set(seen) == {"staged"} and "chosen" not in tm["plain_route_rates_gb_s"]
+    assert set(seen) == {"staged"} and tm["plain_route_rates_gb_s"]["chosen"] == "staged" and "mapped" not in tm["plain_route_rates_gb_s"]

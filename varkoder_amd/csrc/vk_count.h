@@ -1105,20 +1105,27 @@ template <int K, bool INDEX>
 __global__ __launch_bounds__(kCountThreads, 8) void vk_aside_kernel(const uint8_t* __restrict__ fastq, const uint64_t* __restrict__ offs,
                                                                      const uint64_t* __restrict__ lens, uint32_t nsamples, uint32_t parts,
                                                                      uint32_t* __restrict__ hist_out, const uint32_t* __restrict__ aside,
-                                                                     uint32_t aside_cap, const uint32_t* __restrict__ aside_n, IndexParams ip) {
+                                                                     uint32_t aside_cap, const uint32_t* __restrict__ aside_n, IndexParams ip,
+                                                                     uint32_t upb) {   // upb: workgroups of the count launch (of ONE sample) that one workgroup here serves
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr uint32_t NCODE = 1u << (2 * K);
     constexpr bool LDSH = NCODE <= kMaxBins;
     __shared__ uint32_t lhist[LDSH ? NCODE : 1];
     __shared__ uint32_t any_list;
-    const uint32_t unit = blockIdx.x;
+    // Round 6: the count launch is many small workgroups per sample now (vkimg.hip, choose_parts); one workgroup HERE zeroes
+    // and flushes a 64 KB histogram whatever it finds to count, so it serves `upb` of them (all of one sample) in turn.
+    const uint32_t ablocks = (parts + upb - 1u) / upb;
+    const uint32_t smp = blockIdx.x / ablocks;
+    const uint32_t part0 = (blockIdx.x % ablocks) * upb, part1 = part0 + upb < parts ? part0 + upb : parts;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tid >> 6)));
-    const uint32_t gw = unit * kWaves + wave;   // wave of the count launch
-    const uint32_t naside = aside_n[gw];
     if (tid == 0) any_list = 0u;
     __syncthreads();
-    if (naside != 0u && (tid & 63u) == 0u) any_list = 1u;
+    {
+        uint32_t any = 0u;
+        for (uint32_t part = part0; part < part1; ++part) any |= aside_n[(smp * parts + part) * kWaves + wave];
+        if (any != 0u && (tid & 63u) == 0u) any_list = 1u;
+    }
     __syncthreads();
     if (any_list == 0u) return;                 // (uniform for the workgroup: most workgroups of a launch on ordinary reads)
     if constexpr (LDSH) {
@@ -1126,17 +1133,20 @@ __global__ __launch_bounds__(kCountThreads, 8) void vk_aside_kernel(const uint8_
         __syncthreads();
     }
     const uint32_t lhist_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)lhist));
-    const uint32_t smp = unit / parts, part = unit % parts;
-    const WaveRange wr = wave_range(lens[smp], parts, part, static_cast<int>(wave));
     const uint8_t* sbase = fastq + offs[smp];
+    uint32_t* hist = hist_out + static_cast<uint64_t>(smp) * NCODE;
+    const uint32_t lane = tid & 63u;
+    const uint32_t ent = lane / 3u, j = lane - 3u * ent;
+    for (uint32_t part = part0; part < part1; ++part) {
+    const uint32_t unit = smp * parts + part;
+    const uint32_t gw = unit * kWaves + wave;   // wave of the count launch
+    const uint32_t naside = aside_n[gw];
+    const WaveRange wr = wave_range(lens[smp], parts, part, static_cast<int>(wave));
     const uint64_t o0 = wr.w0 != 0 ? wr.w0 - 64 : 0;
     const uint64_t span = wr.w1 - o0;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(sbase + o0), 0, static_cast<int>((span + 15) & ~15ull), 0x00020000);
     const uint32_t* list = aside + static_cast<uint64_t>(gw) * aside_cap;
-    uint32_t* hist = hist_out + static_cast<uint64_t>(smp) * NCODE;
-    const uint32_t lane = tid & 63u;
-    const uint32_t ent = lane / 3u, j = lane - 3u * ent;
     uint32_t* iseg = nullptr;
     uint32_t icap = 0, nanch = 0, isites = 0;
     bool ifull = false;
@@ -1206,6 +1216,7 @@ __global__ __launch_bounds__(kCountThreads, 8) void vk_aside_kernel(const uint8_
             if (ifull) atomicOr(&ip.overflow[smp], 1u);
         }
     }
+    }   // (the units of this workgroup)
     if constexpr (LDSH) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the hand-written ds_add are invisible to hipcc
         __syncthreads();

@@ -218,20 +218,24 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
         int rc = ensure(ctx, reinterpret_cast<void**>(&ctx->d_aside), &ctx->aside_cap, need);
         if (rc) return rc;
         uint32_t* const d_aside_n = ctx->d_aside + nwaves * cap;
+        // vk_aside_kernel: about a thousand workgroups, each serving `upb` workgroups of the count launch (of one sample)
+        const uint32_t awant = nsamples >= 1024u ? 1u : (1024u + nsamples - 1u) / nsamples;
+        const uint32_t upb = (parts + (awant < parts ? awant : parts) - 1u) / (awant < parts ? awant : parts);
+        const uint32_t ablocks = (parts + upb - 1u) / upb;
         if (index) {   // the count and the read index of the samples in one pass (vk_count_index_device)
             hipLaunchKernelGGL((vk_count_dense_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
                                static_cast<uint32_t>(cap), d_aside_n, *index);
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K, true>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, *index);
+            hipLaunchKernelGGL((vk_aside_kernel<K, true>), dim3(nsamples * ablocks), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, *index, upb);
         } else {
             hipLaunchKernelGGL((vk_count_dense_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
                                static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
             VK_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(grid), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
+            hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(nsamples * ablocks), dim3(kCountThreads), 0, ctx->stream, d_fastq,
+                               d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, IndexParams{}, upb);
         }
     }
     VK_HIP(ctx, hipGetLastError());
@@ -414,7 +418,7 @@ int launch_spill(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                d_lens + s0, n, parts, pk, wph0, ctx->d_aside, aside_cap, d_aside_n);
             VK_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream, d_fastq,
-                               d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n, IndexParams{});
+                               d_offs + s0, d_lens + s0, n, parts, hist0, ctx->d_aside, aside_cap, d_aside_n, IndexParams{}, 1u);
             VK_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL((vk_bucket_kernel<K, 2>), dim3(n * parts), dim3(kCountThreads), 0, ctx->stream,
                                d_fastq, d_offs + s0, d_lens + s0, n, parts, hist0, wph0, bp, SubParams{}, pk);

@@ -44,19 +44,23 @@ class RouteChooser:
         from . import engine as E
         self.eng, self.tm, self.E = eng, tm, E
         self.on = E.USE_MAPPED_UPLOAD is None and getattr(eng, "route_override", None) is None and hasattr(eng, "h2d_link_rate")
+        if getattr(eng, "route_rates", None):    # (an earlier pass of this engine measured and chose: say so in this pass's record)
+            tm["plain_route_rates_gb_s"] = dict(eng.route_rates)
         self.rate = {}          # route -> [plain bytes, seconds] over the batches that count
         self.first = None       # the route the run began on
         self.trial_from = None  # batch at which the other route's trial began
 
     def batch_done(self, bi, staged, seconds):
-        if not self.on or bi == 0:   # (the first batch is a short one)
-            return
         if not isinstance(staged, dict) or "disk" not in staged:
+            return
+        if not self.on or bi == 0:   # (the first batch is a short one)
+            self.tm["plain_route"] = staged.get("plain_route", "staged")
             return
         plain = int(staged["disk"][~staged["is_gz"]].sum()) if len(staged["disk"]) else 0
         if plain == 0:
             return
         route = staged.get("plain_route", "staged")   # (as stage_files brought this batch in)
+        self.tm["plain_route"] = route
         acc = self.rate.setdefault(route, [0, 0.0])
         acc[0] += plain
         acc[1] += seconds
@@ -72,12 +76,16 @@ class RouteChooser:
                     self.eng.route_override = other
                     self.trial_from = bi
                 else:
+                    self.eng.route_override = route   # (settled: later passes of this engine do not measure again)
+                    self.tm["plain_route_rates_gb_s"]["chosen"] = route
                     self.on = False
+                self.eng.route_rates = dict(self.tm["plain_route_rates_gb_s"])
         elif other in self.rate and bi >= self.trial_from + 4:   # (the batch staged before the switch went the old way)
             a, b = self.rate[self.first], self.rate[other]
             best = other if b[0] / b[1] > a[0] / a[1] else self.first
             self.eng.route_override = best
             self.tm["plain_route_rates_gb_s"].update({other: b[0] / b[1] / 1e9, "chosen": best})
+            self.eng.route_rates = dict(self.tm["plain_route_rates_gb_s"])
             self.on = False
 
 

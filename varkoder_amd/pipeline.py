@@ -14,7 +14,7 @@ from pathlib import Path
 
 from .config import QUAL_THRESH
 from .image import counts_name, eprint, png_name, shard_folder, write_png
-from .shard import TailQueue, agreed_weights, gz_text_bytes, shard_by_size, split_head_tail
+from .shard import TailQueue, agreed_weights, file_weights, gz_text_bytes, shard_by_size, split_head_tail
 
 
 # Text bytes in HBM per batch.  Plain files: small enough that reading the next batch from disk overlaps
@@ -36,9 +36,9 @@ class RouteChooser:
     pinned buffer, one DMA per batch -- or MAPPED -- the files' page-cache pages are mapped and the GPU copies out of
     them, no read() at all.  Which is faster depends on the host: with 16 fast cores the staged route runs at the link's
     rate (BENCH_r04: 56 of 57.6 GB/s); on a slower host the read() copies -- and the memory bandwidth they take from the DMA
-    -- hold it at 44 (BENCH_r05).  So the run measures itself: batches 1-3 on the route it starts with; if they moved
-    less than 85 % of what the link carries (measured once, 128 MiB pinned -> device), batches 5-7 on the other route,
-    and the rest on whichever was faster.  VARKODER_AMD_MMAP=0/1 pins the route and switches this off."""
+    -- hold it at 44 (BENCH_r05).  So the run measures itself: three batches on the route it starts with (behind two that
+    do not count); if they moved less than 85 % of what the link carries (measured once, 128 MiB pinned -> device), the
+    same on the other route, and the rest on whichever was faster.  VARKODER_AMD_MMAP=0/1 pins the route and switches this off."""
 
     def __init__(self, eng, tm):
         from . import engine as E
@@ -46,41 +46,48 @@ class RouteChooser:
         self.on = E.USE_MAPPED_UPLOAD is None and getattr(eng, "route_override", None) is None and hasattr(eng, "h2d_link_rate")
         if getattr(eng, "route_rates", None):    # (an earlier pass of this engine measured and chose: say so in this pass's record)
             tm["plain_route_rates_gb_s"] = dict(eng.route_rates)
-        self.rate = {}          # route -> [plain bytes, seconds] over the batches that count
+        self.rate = {}          # route -> [plain bytes, seconds, batches] over the batches that count
+        self.seen = {}          # route -> batches seen
         self.first = None       # the route the run began on
-        self.trial_from = None  # batch at which the other route's trial began
+        self.trial = False      # the other route is being tried
 
     def batch_done(self, bi, staged, seconds):
         if not isinstance(staged, dict) or "disk" not in staged:
             return
-        if not self.on or bi == 0:   # (the first batch is a short one)
-            self.tm["plain_route"] = staged.get("plain_route", "staged")
+        route = staged.get("plain_route", "staged")   # (as stage_files brought this batch in)
+        self.tm["plain_route"] = route
+        if not self.on:
             return
         plain = int(staged["disk"][~staged["is_gz"]].sum()) if len(staged["disk"]) else 0
         if plain == 0:
             return
-        route = staged.get("plain_route", "staged")   # (as stage_files brought this batch in)
-        self.tm["plain_route"] = route
-        acc = self.rate.setdefault(route, [0, 0.0])
+        # the first two batches of a route do not count: the run's short first batch, the pinned staging buffers growing to
+        # their size, the first registrations of mapped pages (BENCH r06, first cut: 21.8 GB/s "measured" for the staged route
+        # in a pass that then ran at 51)
+        self.seen[route] = self.seen.get(route, 0) + 1
+        if self.seen[route] <= 2:
+            return
+        acc = self.rate.setdefault(route, [0, 0.0, 0])
         acc[0] += plain
         acc[1] += seconds
+        acc[2] += 1
         if self.first is None:
             self.first = route
         other = "staged" if self.first == "mapped" else "mapped"
-        if self.trial_from is None:
-            if bi >= 3 and route == self.first:
+        if not self.trial:
+            if route == self.first and acc[2] >= 3:
                 link = self.eng.h2d_link_rate()
                 got = acc[0] / acc[1]
                 self.tm["plain_route_rates_gb_s"] = {route: got / 1e9, "link": link / 1e9}
                 if got < 0.85 * link:
                     self.eng.route_override = other
-                    self.trial_from = bi
+                    self.trial = True
                 else:
                     self.eng.route_override = route   # (settled: later passes of this engine do not measure again)
                     self.tm["plain_route_rates_gb_s"]["chosen"] = route
                     self.on = False
                 self.eng.route_rates = dict(self.tm["plain_route_rates_gb_s"])
-        elif other in self.rate and bi >= self.trial_from + 4:   # (the batch staged before the switch went the old way)
+        elif route == other and acc[2] >= 3:
             a, b = self.rate[self.first], self.rate[other]
             best = other if b[0] / b[1] > a[0] / a[1] else self.first
             self.eng.route_override = best
@@ -106,8 +113,8 @@ def fastqs_to_images(files, outdir, k=7, mapping_code="cgr", labels=None, base_s
     files = [Path(f) for f in files]
     labels = labels or {}
     base_sd = base_sd or {}
-    if weights is None:
-        weights = agreed_weights(files)
+    if weights is None:   # (a collective only when this call itself is one rank's share of a job: bench.py's per-rank legs call with world = 1 inside a group)
+        weights = agreed_weights(files) if world > 1 else file_weights(files)
     # Size-aware (rank 0's view of the sizes: shard.agreed_weights).  With a process group, the longest files -- nine tenths
     # of the weight -- are dealt statically, and the many small ones at the end of the order are pulled from a shared
     # cursor by whichever rank gets there first (shard.split_head_tail, TailQueue): the deal balances estimates, the
@@ -273,7 +280,7 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
     files = [Path(f) for f in files]
     labels, base_sd, seeds = labels or {}, base_sd or {}, seeds or {}
     if weights is None:
-        weights = agreed_weights(files)   # (a collective: see fastqs_to_images)
+        weights = agreed_weights(files) if world > 1 else file_weights(files)   # (a collective when sharded: see fastqs_to_images)
     mine = [files[i] for i in shard_by_size(weights, rank, world)]   # size-aware; rank 0's view of the sizes: see shard.agreed_weights
     eng = engine or ImageEngine(k=k, mapping=mapping_code, device=device)
     outdir = Path(outdir)
@@ -283,62 +290,68 @@ def clean_to_images(files, outdir, k=7, mapping_code="cgr", min_bp=50000, max_bp
     pending = []
     if batch_bytes is None:
         batch_bytes = DEFAULT_GZ_BATCH_BYTES if mine and all(f.suffix == ".gz" for f in mine) else DEFAULT_BATCH_BYTES
-    i = 0
-    while i < len(mine):
-        batch, nbytes = [], 0
-        t0 = time.perf_counter()
-        for f in mine[i:]:
-            sz = gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
-            if batch and nbytes + sz > batch_bytes:
-                break
-            batch.append(f)
-            nbytes += sz
-        i += len(batch)
-        names = [str(f.name.removesuffix("".join(f.suffixes))) for f in batch]
-        dev, offs, lens = eng.upload_files(batch, pool)
-        recs = []
-        # one seed per launch: samples with different seeds go in separate calls
-        by_seed = OrderedDict()
-        for j, s in enumerate(names):
-            by_seed.setdefault(int(seeds.get(s, 0)), []).append(j)
-        recs = [None] * len(batch)
-        for seed, idx in by_seed.items():
-            for j, r in zip(idx, ladder_counts(eng, dev, offs[idx], lens[idx], seed=seed, min_bp=min_bp,
-                                               max_bp=max_bp, is_query=is_query)):
-                recs[j] = r
-        t1 = time.perf_counter()
-        flat = [(j, bp, h) for j, r in enumerate(recs) for bp, h, _ in r["steps"]]
-        imgs = eng.images(torch.stack([h for _, _, h in flat])).cpu().numpy() if flat else []
-        nz = [bool((h != 0).any().item()) for _, _, h in flat]
-        t2 = time.perf_counter()
-        for j, s in enumerate(names):
-            st = stats.setdefault(s, OrderedDict())
-            if recs[j]["error"]:
-                eprint("SPLIT FAIL:", batch[j], "-", recs[j]["error"])
-                st["failed_step"] = "split"
-                continue
-            st["splitting_time"] = (t1 - t0) / len(batch)
-            st["splitting_bp_per_file"] = ",".join(str(bp) for bp, _, _ in recs[j]["steps"])
-            st[str(k) + "mer_counting_time"] = (t1 - t0) / len(batch)
-        for n, (j, bp, _) in enumerate(flat):
-            s = names[j]
-            if not nz[n]:
-                eprint("IMAGE FAIL:", split_name(s, bp))
-                stats[s]["failed_step"] = "image"
-                continue
-            name = png_name(split_name(s, bp) + "+k" + str(k) + ".fq.h5", mapping_code)
-            d = shard_folder(outdir, name, subfolder_levels)
-            d.mkdir(parents=True, exist_ok=True)
-            pending.append((s, time.perf_counter(),
-                            pool.submit(write_png, imgs[n].copy(), d / name, labels.get(s, []), base_sd.get(s, 0),
-                                        QUAL_THRESH, mapping_code)))
-        if verbose:
-            eprint(f"batch of {len(batch)} samples, {nbytes} bytes: upload+ladder {t1 - t0:.3f}s images {t2 - t1:.3f}s")
-    for s, t, fut in pending:
-        fut.result()
-        key = "k" + str(k) + "_img_time"
-        stats[s][key] = stats[s].get(key, 0) + (time.perf_counter() - t)
-    pool.shutdown()
+    done = False
+    try:   # (an error below must not leave the pool writing PNGs into outdir behind the caller's back: see fastqs_to_images)
+        i = 0
+        while i < len(mine):
+            batch, nbytes = [], 0
+            t0 = time.perf_counter()
+            for f in mine[i:]:
+                sz = gz_text_bytes(f) if f.suffix == ".gz" else os.path.getsize(f)
+                if batch and nbytes + sz > batch_bytes:
+                    break
+                batch.append(f)
+                nbytes += sz
+            i += len(batch)
+            names = [str(f.name.removesuffix("".join(f.suffixes))) for f in batch]
+            dev, offs, lens = eng.upload_files(batch, pool)
+            recs = []
+            # one seed per launch: samples with different seeds go in separate calls
+            by_seed = OrderedDict()
+            for j, s in enumerate(names):
+                by_seed.setdefault(int(seeds.get(s, 0)), []).append(j)
+            recs = [None] * len(batch)
+            for seed, idx in by_seed.items():
+                for j, r in zip(idx, ladder_counts(eng, dev, offs[idx], lens[idx], seed=seed, min_bp=min_bp,
+                                                   max_bp=max_bp, is_query=is_query)):
+                    recs[j] = r
+            t1 = time.perf_counter()
+            flat = [(j, bp, h) for j, r in enumerate(recs) for bp, h, _ in r["steps"]]
+            imgs = eng.images(torch.stack([h for _, _, h in flat])).cpu().numpy() if flat else []
+            nz = [bool((h != 0).any().item()) for _, _, h in flat]
+            t2 = time.perf_counter()
+            for j, s in enumerate(names):
+                st = stats.setdefault(s, OrderedDict())
+                if recs[j]["error"]:
+                    eprint("SPLIT FAIL:", batch[j], "-", recs[j]["error"])
+                    st["failed_step"] = "split"
+                    continue
+                st["splitting_time"] = (t1 - t0) / len(batch)
+                st["splitting_bp_per_file"] = ",".join(str(bp) for bp, _, _ in recs[j]["steps"])
+                st[str(k) + "mer_counting_time"] = (t1 - t0) / len(batch)
+            for n, (j, bp, _) in enumerate(flat):
+                s = names[j]
+                if not nz[n]:
+                    eprint("IMAGE FAIL:", split_name(s, bp))
+                    stats[s]["failed_step"] = "image"
+                    continue
+                name = png_name(split_name(s, bp) + "+k" + str(k) + ".fq.h5", mapping_code)
+                d = shard_folder(outdir, name, subfolder_levels)
+                d.mkdir(parents=True, exist_ok=True)
+                pending.append((s, time.perf_counter(),
+                                pool.submit(write_png, imgs[n].copy(), d / name, labels.get(s, []), base_sd.get(s, 0),
+                                            QUAL_THRESH, mapping_code)))
+            if verbose:
+                eprint(f"batch of {len(batch)} samples, {nbytes} bytes: upload+ladder {t1 - t0:.3f}s images {t2 - t1:.3f}s")
+        for s, t, fut in pending:
+            fut.result()
+            key = "k" + str(k) + "_img_time"
+            stats[s][key] = stats[s].get(key, 0) + (time.perf_counter() - t)
+        done = True
+    finally:
+        pool.shutdown(wait=True, cancel_futures=not done)
+        if not done and engine is None:
+            eng.close()
     if engine is None:
         eng.close()
     return stats

@@ -61,11 +61,11 @@ class RouteChooser:
         plain = int(staged["disk"][~staged["is_gz"]].sum()) if len(staged["disk"]) else 0
         if plain == 0:
             return
-        # the first two batches of a route do not count: the run's short first batch, the pinned staging buffers growing to
+        # the first batches of a route do not count: the run's short first batch, the pinned staging buffers growing to
         # their size, the first registrations of mapped pages (BENCH r06, first cut: 21.8 GB/s "measured" for the staged route
         # in a pass that then ran at 51)
         self.seen[route] = self.seen.get(route, 0) + 1
-        if self.seen[route] <= 2:
+        if self.seen[route] <= (3 if not self.trial else 2):   # (batch 0 is short; each of the two staging buffers grows once more after it)
             return
         acc = self.rate.setdefault(route, [0, 0.0, 0])
         acc[0] += plain

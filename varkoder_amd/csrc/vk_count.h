@@ -1464,8 +1464,18 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
                 gs.pph = pph; gs.hot = hot ? 1u : 0u; gs.tick = tick;
                 gs.nanch = nanch; gs.full = 0u; gs.sites = 0u;
                 const uint32_t valid = (it + 1 == npieces && tail_bytes != 0u) ? tail_bytes : static_cast<uint32_t>(kPiece);
+#ifdef VK_DIAG_NO_GENERAL   // timing only (results wrong): the loop without its one function call -- the piece's newlines still counted, so that the line phase stays right
+                {
+                    const uint32_t c = nl_count16(q0) + nl_count16(q1) + nl_count16(q2) + nl_count16(q3);
+                    const uint32_t incl = wave_inclusive_sum(c);
+                    if (it == 0) gs.pph = has_pre ? ph0 - lane_bcast(c, 0) : 0u;
+                    gs.pph += lane_bcast(incl, 63);
+                    gs.ctx_bad = 0x55555555u;
+                }
+#else
                 gs = general_piece<K, INDEX>(q0, q1, q2, q3, gs, (it == 0 ? 1u : 0u) | (has_pre ? 2u : 0u) | (ph0 << 2) | (valid << 4),
                                              hist, hist_base, iseg, icap, static_cast<uint32_t>(o0) + it * static_cast<uint32_t>(kPiece));
+#endif
                 if constexpr (INDEX) {
                     nanch = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gs.nanch)));
                     if (__builtin_amdgcn_readfirstlane(static_cast<int>(gs.full)) != 0) ifull = true;

@@ -582,3 +582,24 @@ def test_tandem_repeats_of_every_short_period_stay_exact(engines, k):
         assert np.array_equal(got[0], wants[0]), (k, parts)
         assert np.array_equal(got[1], wants[1]), (k, parts)
         assert np.array_equal(got[2], wants[0]), (k, parts)
+
+
+def test_aside_kernel_serves_several_count_workgroups_of_a_sample(engines):
+    """Round 6: the count launch is many workgroups per sample and vk_aside_kernel serves several of them (all of one
+    sample) per workgroup of its own -- about a thousand in all, so the grouping only happens in launches of a thousand
+    workgroups and more.  1100 copies of a few blobs full of short reads (lanes set aside in nearly every piece) at 3 and
+    at 7 workgroups per sample: every histogram equals the oracle's."""
+    k = 7
+    eng = engines(k)
+    blobs = [b for b in _dense_blobs() if len(b) > 300_000][:6]
+    want = [oracle.count_fastq(b, k)[0] for b in blobs]
+    dev, offs, lens = eng.upload(blobs)
+    n = 1100
+    idx = np.arange(n) % len(blobs)
+    o, l = offs[idx].copy(), lens[idx].copy()
+    for parts in (3, 7):
+        hist, status = eng.count(dev, o, l, parts=parts)
+        assert not status.cpu().numpy().any(), parts
+        got = hist.cpu().numpy().view(np.uint32)
+        bad = [i for i in range(n) if not np.array_equal(got[i], want[idx[i]])]
+        assert not bad, (parts, bad[:8])

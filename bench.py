@@ -784,6 +784,62 @@ def query_leg(args, device_index):
             "verified_preprocess_images": verified, "dtype": "u32 counts, u8 images, float32 transform and forward"}
 
 
+class ClockSampler:
+    """The GPU's shader clock while the timed steps run: the starred line of the card's `pp_dpm_sclk` (found by the device's
+    PCI address), read every 10 ms by a host thread.  Boxes of the pool run the same binary a few per cent apart; with the
+    clock in the record a slow box can be told from a slow kernel.  Never raises: {"error": ...} when the file is not there."""
+
+    def __init__(self, device_index):
+        import threading
+        self.path, self.err, self.vals, self.stop_flag, self.thread = None, None, [], threading.Event(), None
+        try:
+            import glob
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            cand = glob.glob("/sys/bus/pci/devices/%s/pp_dpm_sclk" % bdf)
+            if cand:
+                self.path = cand[0]
+            else:
+                self.err = "no pp_dpm_sclk for PCI device %s" % bdf
+        except Exception as e:  # noqa: BLE001
+            self.err = repr(e)
+
+    def read(self):
+        with open(self.path) as f:
+            for line in f:
+                if "*" in line:
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+        return None
+
+    def start(self):
+        if self.path is None:
+            return
+        import threading
+
+        def run():
+            while not self.stop_flag.is_set():
+                try:
+                    v = self.read()
+                    if v:
+                        self.vals.append(v)
+                except Exception as e:  # noqa: BLE001
+                    self.err = repr(e)
+                    return
+                self.stop_flag.wait(0.01)
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def stop(self):
+        if self.thread is not None:
+            self.stop_flag.set()
+            self.thread.join(timeout=2.0)
+        if not self.vals:
+            return {"error": self.err or "no samples"}
+        v = sorted(self.vals)
+        return {"samples": len(v), "min": v[0], "median": v[len(v) // 2], "max": v[-1], "source": self.path}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -918,11 +974,14 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    clocks = ClockSampler(local_rank)      # (a host thread reading one sysfs file every 10 ms: nothing on the GPU's side)
+    clocks.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(ev[i])
     fence()
     elapsed = time.perf_counter() - t0
+    sclk = clocks.stop()
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         mine = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -1004,6 +1063,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": count_ms,
                          "count_ms_by_step": [float(e[0].elapsed_time(e[1])) for e in ev],
+                         "shader_clock_mhz_during_timed_steps": sclk,
                          "traffic_source": "from_profile_file (profiles/traffic_latest.json: separate rocprofv3 --pmc passes "
                                            "of this configuration); achieved / avg_launch_ms are this run's HIP events"},
         }

@@ -55,6 +55,48 @@ def test_every_rule_fires():
     assert findings("\tv_dot4_u32_u8 v5, v1, v2, v3\n.LBB0_2:\n\t;;#ASMSTART\n\tv_lshl_or_b32 v6, v5, 1, v7\n\t;;#ASMEND\n") == []
 
 
+DIVERGED = """
+walker:
+.LBB0_1:                                ; =>This Loop Header: Depth=1
+                                        ;     Child Loop BB0_2 Depth 2
+	s_mov_b64 s[42:43], s[4:5]
+.LBB0_2:                                ;   Parent Loop BB0_1 Depth=1
+                                        ; =>  This Inner Loop Header: Depth=2
+	v_mov_b32_e32 v3, 0
+	s_nop 1
+	v_mov_b32_dpp v3, v33 row_shr:1 row_mask:0xf bank_mask:0xf
+	v_cmp_lt_u32_e64 s[44:45], s67, v33
+; %bb.3:                                ;   in Loop: Header=BB0_2 Depth=2
+	s_or_b64 s[36:37], s[44:45], s[36:37]
+	s_andn2_b64 exec, exec, s[36:37]
+	s_cbranch_execnz .LBB0_2
+; %bb.4:                                ;   in Loop: Header=BB0_1 Depth=1
+	s_or_b64 exec, exec, s[36:37]
+	global_atomic_add v3, v22, s[18:19]
+	s_cbranch_vccnz .LBB0_1
+; %bb.5:
+	s_endpgm
+"""
+
+
+def test_cross_lane_operations_in_a_loop_the_compiler_made_divergent_are_found():
+    """the walker at k = 8, 9 without its latch barrier: the lanes with a sixteenth window wait at the outer
+    latch while the others run the next trip's DPP moves"""
+    found = asm_lint.convergence(DIVERGED.splitlines())
+    assert [(fn, h, len(ops)) for fn, h, _, ops in found] == [("walker", "BB0_2", 1)]
+    # the same loop left by a scalar branch: nothing to report; a divergent loop without cross-lane operations neither
+    uniform = DIVERGED.replace("\ts_andn2_b64 exec, exec, s[36:37]\n\ts_cbranch_execnz .LBB0_2", "\ts_cbranch_vccnz .LBB0_2")
+    assert asm_lint.convergence(uniform.splitlines()) == []
+    plain = DIVERGED.replace("v_mov_b32_dpp v3, v33 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_e32 v3, v33")
+    assert asm_lint.convergence(plain.splitlines()) == []
+    # an operation in a loop NESTED in the divergent one counts; one in the enclosing loop does not
+    outer = DIVERGED.replace("\tglobal_atomic_add v3, v22, s[18:19]", "\tv_readlane_b32 s5, v2, 3")
+    assert [h for _, h, _, _ in asm_lint.convergence(outer.splitlines())] == ["BB0_2"]
+    inner_only = plain.replace("\ts_cbranch_vccnz .LBB0_1", "\ts_andn2_b64 exec, exec, s[30:31]\n\ts_cbranch_execnz .LBB0_1") \
+        .replace("v_mov_b32_e32 v3, v33", "ds_bpermute_b32 v3, v4, v33")
+    assert sorted(h for _, h, _, _ in asm_lint.convergence(inner_only.splitlines())) == ["BB0_1", "BB0_2"]
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
 def test_shipped_kernels_have_no_unpadded_asm_hazard():
     path = asm_lint.device_asm()
@@ -63,3 +105,7 @@ def test_shipped_kernels_have_no_unpadded_asm_hazard():
     assert sum(1 for l in lines if ";;#ASMSTART" in l) > 1000        # the hand-written blocks are in there
     found = asm_lint.lint(lines)
     assert not found, [(fn, rule, p.text, c.text) for fn, rule, _, _, p, c in found[:5]]
+    # ... and no DPP move, v_readlane or permute in a loop that hipcc wrote as one the lanes leave one by one
+    assert sum(1 for l in lines if "_dpp" in l or "v_readlane" in l or "ds_bpermute" in l) > 500
+    conv = asm_lint.convergence(lines)
+    assert not conv, [(fn, h, ops[:2]) for fn, h, _, ops in conv[:5]]

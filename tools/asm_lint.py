@@ -198,6 +198,92 @@ def check(p, c):
     return out
 
 
+CROSS = re.compile(r"^(v_readlane|v_writelane|ds_bpermute|ds_permute|ds_swizzle|v_permlane)")
+BLOCK = re.compile(r"^(\.LBB\d+_\d+):|^; %bb\.\d+:")
+HDR = re.compile(r"Loop Header: Depth=(\d+)")
+PARENT = re.compile(r"Parent Loop (BB\d+_\d+) Depth=(\d+)")
+INLOOP = re.compile(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)")
+
+
+def convergence(lines):
+    """Cross-lane operations inside a loop that hipcc has made DIVERGENT.
+
+    A loop whose lanes leave one by one ends in `s_andn2_b64 exec, exec, <left>` + `s_cbranch_exec(n)z` (SI_LOOP); a loop
+    that is uniform in the source -- its condition a ballot, its body full of DPP moves, v_readlane, ballots -- must not
+    come out that way.  It did once (the walker at k = 8, 9): the body ended in a per-lane `if`, the
+    arithmetic behind the `if` was duplicated into both of its exits, the two exits became two back edges, the two back
+    edges an inner and an outer loop, and the lanes that took the inner one ran the next trip's ballot and DPP moves
+    while the others waited at the outer latch.  The loop structure is read from the comments hipcc writes at every block
+    ("in Loop: Header=BBx_y Depth=d", "Parent Loop ...", "Loop Header: Depth=d"); instructions inside asm statements
+    count as cross-lane when they are DPP, v_readlane/v_writelane or permutes.  Returns [(function, header label,
+    line of the loop's exec update, [cross-lane instruction texts ...])]."""
+    found = []
+    fn = None
+    parent = {}        # header label -> enclosing header label (None at depth 1)
+    divergent = {}     # header label -> line number of its exec update
+    body = {}          # header label (innermost) -> [(line, text)] cross-lane instructions
+    cur = None         # innermost loop of the current block
+    pending = None     # a block label whose comment lines are still being read
+
+    def flush():
+        for h, at in sorted(divergent.items(), key=lambda kv: kv[1]):
+            inside = []
+            for b, ins in body.items():
+                a = b
+                while a is not None and a != h:
+                    a = parent.get(a)
+                if a == h:
+                    inside += ins
+            if inside:
+                found.append((fn, h, at, [t for _, t in sorted(inside)]))
+
+    for n, raw in enumerate(lines, 1):
+        s = raw.strip()
+        m = re.match(r"^([A-Za-z_$][\w.$]*):", s)
+        if m and not m.group(1).startswith(("L", ".L")):
+            if fn is not None:
+                flush()
+            fn, parent, divergent, body, cur, pending = m.group(1), {}, {}, {}, None, None
+            continue
+        b = BLOCK.match(s)
+        if b or (pending and s.startswith(";") and not s.startswith(";;#")):
+            if b:
+                pending = (b.group(1) or "").lstrip(".L") and b.group(1)[2:] if b.group(1) else "bb"
+                cur = None
+                parents = []
+            il = INLOOP.search(s)
+            if il:
+                cur = il.group(1)
+            for pm in PARENT.finditer(s):
+                parents.append((int(pm.group(2)), pm.group(1)))
+            if HDR.search(s) and pending not in (None, "bb"):
+                d = int(HDR.search(s).group(1))
+                above = [lab for dep, lab in parents if dep == d - 1]
+                parent[pending] = above[0] if above else None
+                cur = pending
+            if b and not s.startswith(";"):
+                rest = s.split(":", 1)[1]
+                if not rest.strip().startswith(";"):
+                    pending = None
+            continue
+        pending = None
+        if not s or s.startswith((".", ";")) and ";;#" not in s:
+            continue
+        if ";;#" in s:
+            continue
+        text = s.split(";")[0].strip()
+        if not text or cur is None:
+            continue
+        op = text.split(None, 1)[0]
+        if op == "s_andn2_b64" and re.match(r"^s_andn2_b64\s+exec,\s*exec,", text):
+            divergent.setdefault(cur, n)
+        elif CROSS.match(op) or DPP.search(text):
+            body.setdefault(cur, []).append((n, text))
+    if fn is not None:
+        flush()
+    return found
+
+
 def device_asm():
     out = os.path.join(tempfile.mkdtemp(prefix="vk_lint_"), "vkimg.s")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-S",
@@ -216,8 +302,13 @@ def main(argv):
         print(f"{fn}: {rule}: {need} wait states needed, {waited} present")
         print(f"    line {p.line}{' (asm)' if p.in_asm else ''}: {p.text}")
         print(f"    line {c.line}{' (asm)' if c.in_asm else ''}: {c.text}")
-    print(f"asm_lint: {nasm} asm statements, {len(found)} findings in {path}")
-    return 1 if found else 0
+    conv = convergence(lines)
+    for fn, header, at, ops in conv:
+        print(f"{fn}: loop {header} leaves its lanes one by one (line {at}) and holds {len(ops)} cross-lane operations, e.g.")
+        for t in ops[:3]:
+            print(f"    {t}")
+    print(f"asm_lint: {nasm} asm statements, {len(found)} hazard findings, {len(conv)} divergent loops with cross-lane operations in {path}")
+    return 1 if found or conv else 0
 
 
 if __name__ == "__main__":

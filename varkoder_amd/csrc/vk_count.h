@@ -290,7 +290,12 @@ __device__ __forceinline__ bool probe_few_groups(uint32_t addr, unsigned long lo
 }
 
 // The two probes together; `tick` counts the calls of one wave.
-__device__ __forceinline__ bool probe_low_complexity(uint32_t addr, unsigned long long mask, uint32_t& tick) {
+__device__ __forceinline__ bool probe_low_complexity(uint32_t addr, unsigned long long mask_in, uint32_t& tick) {
+    // (the mask is a ballot, one value for the wave, but general_piece has it behind a branch on a by-value argument and
+    // hipcc keeps it in vector registers there: the probes' loop over groups then came out as a loop the lanes leave
+    // one by one, with its v_readlane inside; a scalar again at no cost where it already was one)
+    const unsigned long long mask = static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(mask_in)))) |
+        static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(mask_in >> 32)))) << 32;
     if (probe_is_hot(addr, mask)) return true;
     return ((++tick) & 15u) == 0u && probe_few_groups(addr, mask);
 }
@@ -2530,7 +2535,12 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
         return at;
     };
     const uint32_t njobs_up = (njobs + 1023u) / 1024u * 1024u;   // (whole wavefronts take part in the ballots)
-    for (uint32_t j = tid; j < njobs_up; j += 1024) grouped(j < njobs ? cls(bp.bsize[j]) : 0u, j < njobs, cnt);
+    // (the loops count in a scalar: `j = tid; j < njobs_up; j += 1024` is a loop the lanes may leave one by one as far as
+    // hipcc can tell, and the ballots and v_readlane of `grouped` do not belong in one -- tools/asm_lint.py, convergence)
+    for (uint32_t j0 = 0; j0 < njobs_up; j0 += 1024) {
+        const uint32_t j = j0 + tid;
+        grouped(j < njobs ? cls(bp.bsize[j]) : 0u, j < njobs, cnt);
+    }
     __syncthreads();
     if (tid == 0) {
         uint32_t at = 0;
@@ -2540,7 +2550,8 @@ __global__ __launch_bounds__(1024) void vk_bucket_order_kernel(BucketParams bp, 
         }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < njobs_up; j += 1024) {
+    for (uint32_t j0 = 0; j0 < njobs_up; j0 += 1024) {
+        const uint32_t j = j0 + tid;
         const uint32_t at = grouped(j < njobs ? cls(bp.bsize[j]) : 0u, j < njobs, first);
         if (j < njobs) bp.order[at] = j;
     }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kImgThreads) void vk_image_count_kernel(
     }
     uint32_t base = 0;  // values counted by earlier passes
     for (uint32_t pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && any_hi == 0u) break;  // uniform: nothing in [32768, 65536)
+        if (pass == 1 && __builtin_amdgcn_readfirstlane(static_cast<int>(any_hi)) == 0) break;  // uniform (and a scalar for hipcc: a wave scan follows): nothing in [32768, 65536)
         for (uint32_t i = tid; i < kCountBins; i += kImgThreads) cnt[i] = 0u;
         __syncthreads();
         for (uint32_t i = tid; i < npix; i += kImgThreads) {

@@ -629,7 +629,10 @@ __device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hi
             const uint32_t up = __shfl_up(incl, d);
             if (lane >= d) incl += up;
         }
-        const uint32_t total = __shfl(incl, 63);
+        // (a SCALAR: everything the three loops below turn on -- the chunk, the batch, the overflow check -- derives from it, and
+        // with `total` out of a __shfl hipcc had to write all three as loops the lanes may leave one by one, around ballots and
+        // ds_bpermute chains; tools/asm_lint.py, convergence)
+        const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
         const uint64_t off = base + (incl - len);  // where this lane's token starts
         if (base + total > cap) { st |= kGzOverflow; break; }
         // a distance beyond the start of the gzip member is an error

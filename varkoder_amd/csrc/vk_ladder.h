@@ -195,9 +195,6 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_walk_kernel(
                     const uint32_t low = (stop - 1u) & ~stop;                  // everything below my first line end (all ones without one)
                     const uint32_t SEQ = (active && !over) ? (low & ~below_start) : 0u;
                     below_start = 0u;
-                    // (opaque to the optimiser: without this the k = 8, 9 instantiations -- and only those -- counted a few
-                    // windows too many or too few per sample, hipcc 7.2; tests/test_subsample.py::test_walker_at_k8_and_k9)
-                    asm volatile("" : "+v"(below_start));
                     taken_sites += vkl::popc(SEQ & 0x55555555u);
                     const uint32_t bad = (IV | ~SEQ) & 0x55555555u;
                     const uint32_t c_before = dpp_or_zero<0x111, 0xF>(C), bad_before = dpp_or_zero<0x111, 0xF>(bad);   // row_shr:1: the lane before
@@ -233,6 +230,14 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_walk_kernel(
                     r500 = r500 + 64u >= vkl::kBreakLength ? r500 + 64u - vkl::kBreakLength : r500 + 64u;
                     at += 64u;
                     if (quad != 0u || (at & ~63u) >= len32) active = false;   // the line ended in this sector, or the text did
+                    // The lanes meet HERE, not at the loop's head.  For k = 8, 9 the body ends in windows1's per-lane
+                    // `if (ok bit 15) atomicAdd`, and what follows it is plain arithmetic: hipcc 7.2 threaded the two ways
+                    // out of that `if` into two back edges, made an inner and an outer loop of them, and the lanes without
+                    // a sixteenth window ran on through the ballot and the DPP moves at the head while the others waited at
+                    // the outer latch -- context read from lanes outside EXEC, line ends voted by a part of the quad
+                    // (tools/walker_fence_probe.py).  A convergent operation can be neither duplicated into
+                    // the two paths nor made to depend on the `if`, so the body keeps one latch behind the join.
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         };

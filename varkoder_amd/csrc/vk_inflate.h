@@ -623,12 +623,7 @@ __device__ __attribute__((noinline)) GzRes gz_resolve_slabs(GzLdsP L, GzHistP hi
         const uint32_t len = !live ? 0u : (is_match ? (tok & 0x1FFu) : 1u);
         const uint32_t dist = (tok >> 9) & 0xFFFFu;
         // inclusive prefix sum of len over the wave
-        uint32_t incl = len;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
+        const uint32_t incl = wave_inclusive_sum(len);   // (six DPP adds; six __shfl_up were six LDS round trips)
         // (a SCALAR: everything the three loops below turn on -- the chunk, the batch, the overflow check -- derives from it, and
         // with `total` out of a __shfl hipcc had to write all three as loops the lanes may leave one by one, around ballots and
         // ds_bpermute chains; tools/asm_lint.py, convergence)

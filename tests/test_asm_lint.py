@@ -92,6 +92,10 @@ def test_cross_lane_operations_in_a_loop_the_compiler_made_divergent_are_found()
     # an operation in a loop NESTED in the divergent one counts; one in the enclosing loop does not
     outer = DIVERGED.replace("\tglobal_atomic_add v3, v22, s[18:19]", "\tv_readlane_b32 s5, v2, 3")
     assert [h for _, h, _, _ in asm_lint.convergence(outer.splitlines())] == ["BB0_2"]
+    # a hand-written block that sets EXEC and puts it back: the same finding; the compiler's own s_mov_b64 exec is its business
+    by_hand = plain.replace("\tv_mov_b32_e32 v3, v33\n", "\t;;#ASMSTART\n\ts_mov_b64 exec, s[8:9]\n\tds_add_u32 v2, v3\n\ts_mov_b64 exec, s[10:11]\n\t;;#ASMEND\n")
+    assert [(h, len(ops)) for _, h, _, ops in asm_lint.convergence(by_hand.splitlines())] == [("BB0_2", 2)]
+    assert asm_lint.convergence(by_hand.replace("\t;;#ASMSTART\n", "").replace("\t;;#ASMEND\n", "").splitlines()) == []
     inner_only = plain.replace("\ts_cbranch_vccnz .LBB0_1", "\ts_andn2_b64 exec, exec, s[30:31]\n\ts_cbranch_execnz .LBB0_1") \
         .replace("v_mov_b32_e32 v3, v33", "ds_bpermute_b32 v3, v4, v33")
     assert sorted(h for _, h, _, _ in asm_lint.convergence(inner_only.splitlines())) == ["BB0_1", "BB0_2"]

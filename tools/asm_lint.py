@@ -210,12 +210,13 @@ def convergence(lines):
 
     A loop whose lanes leave one by one ends in `s_andn2_b64 exec, exec, <left>` + `s_cbranch_exec(n)z` (SI_LOOP); a loop
     that is uniform in the source -- its condition a ballot, its body full of DPP moves, v_readlane, ballots -- must not
-    come out that way.  It did once (the walker at k = 8, 9): the body ended in a per-lane `if`, the
+    come out that way (nor may one that holds a hand-written `s_mov_b64 exec, ...`: the window blocks set EXEC per window and put
+    back what they read at their head).  It did once (the walker at k = 8, 9): the body ended in a per-lane `if`, the
     arithmetic behind the `if` was duplicated into both of its exits, the two exits became two back edges, the two back
     edges an inner and an outer loop, and the lanes that took the inner one ran the next trip's ballot and DPP moves
     while the others waited at the outer latch.  The loop structure is read from the comments hipcc writes at every block
     ("in Loop: Header=BBx_y Depth=d", "Parent Loop ...", "Loop Header: Depth=d"); instructions inside asm statements
-    count as cross-lane when they are DPP, v_readlane/v_writelane or permutes.  Returns [(function, header label,
+    count as cross-lane when they are DPP, v_readlane/v_writelane, permutes, or write EXEC.  Returns [(function, header label,
     line of the loop's exec update, [cross-lane instruction texts ...])]."""
     found = []
     fn = None
@@ -224,6 +225,7 @@ def convergence(lines):
     body = {}          # header label (innermost) -> [(line, text)] cross-lane instructions
     cur = None         # innermost loop of the current block
     pending = None     # a block label whose comment lines are still being read
+    in_asm = False     # between ;;#ASMSTART and ;;#ASMEND
 
     def flush():
         for h, at in sorted(divergent.items(), key=lambda kv: kv[1]):
@@ -243,7 +245,7 @@ def convergence(lines):
         if m and not m.group(1).startswith(("L", ".L")):
             if fn is not None:
                 flush()
-            fn, parent, divergent, body, cur, pending = m.group(1), {}, {}, {}, None, None
+            fn, parent, divergent, body, cur, pending, in_asm = m.group(1), {}, {}, {}, None, None, False
             continue
         b = BLOCK.match(s)
         if b or (pending and s.startswith(";") and not s.startswith(";;#")):
@@ -270,6 +272,7 @@ def convergence(lines):
         if not s or s.startswith((".", ";")) and ";;#" not in s:
             continue
         if ";;#" in s:
+            in_asm = ";;#ASMSTART" in s
             continue
         text = s.split(";")[0].strip()
         if not text or cur is None:
@@ -277,7 +280,9 @@ def convergence(lines):
         op = text.split(None, 1)[0]
         if op == "s_andn2_b64" and re.match(r"^s_andn2_b64\s+exec,\s*exec,", text):
             divergent.setdefault(cur, n)
-        elif CROSS.match(op) or DPP.search(text):
+        elif CROSS.match(op) or DPP.search(text) or (in_asm and re.match(r"^s_mov_b64\s+exec,", text)):
+            # (a hand-written block that sets EXEC per window and puts back what it read at its head assumes that every lane
+            # that entered the loop is still in it)
             body.setdefault(cur, []).append((n, text))
     if fn is not None:
         flush()

@@ -1588,6 +1588,47 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         ph_end = pph & 3u;
         general_pieces = ngeneral < 0xFFFFFFu ? ngeneral : 0xFFFFFFu;
         aside_count = naside;
+#ifdef VK_DIAG_ASIDE_INLINE
+        // DIAGNOSTIC: round 4's deferred count of the lanes set aside, inlined behind the piece loop instead of a
+        // kernel of its own -- the arrangement that made the K = 5 build lose the loop's own counts.  Not shipped.
+        if constexpr (!INDEX) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the list's stores
+            const uint32_t* list = aside + static_cast<uint64_t>(unit * kWaves + static_cast<uint32_t>(wave)) * aside_cap;
+            const uint32_t ulane = static_cast<uint32_t>(lane);
+            const uint32_t ent = ulane / 3u, j = ulane - 3u * ent;
+            for (uint32_t at = 0; at < naside; at += kSetAsideBatch) {
+                const uint32_t n = naside - at < kSetAsideBatch ? naside - at : kSetAsideBatch;
+                const bool live = ent < n;
+                const uint32_t w = live ? list[at + ent] : 0u;
+                const uint32_t off = live ? ((w >> 3) - 1u + j) * 64u : 0xFFFFFF00u;
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 0);
+                const u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 32, 0);
+                const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 48, 0);
+                const uint32_t d[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w, e4.x, e4.y, e4.z, e4.w};
+                vkl::LaneBits lb;
+                const uint32_t c = vkl::classify<false>(d, lb);
+                const uint32_t cprev = wave_prev_lane(c, 0u);
+                const uint32_t lph = ((w & 3u) + (j == 0u ? 0u - c : (j == 2u ? cprev : 0u))) & 3u;
+                vkl::Mask128 seq;
+                uint32_t s_raw = 0;
+                if (__any(c > 4u)) seq = vkl::seq_mask_general(lb.NL, lph);
+                else seq = vkl::seq_mask_fast4(lb.NL, lph, vkl::ones_below, vkl::ones_not_below, s_raw);
+                uint32_t bad[4], ok[4];
+                vkl::bad_mask(lb, seq, bad);
+                const uint32_t badh = wave_prev_lane(bad[3], 0x55555555u);
+                const uint32_t ch = wave_prev_lane(lb.C[3], 0u);
+                vkl::ok_mask<K>(badh, bad, ok);
+                constexpr uint32_t kBack = (1u << (2 * (K - 1))) - 1u;
+                if (!live || j == 0u) { ok[0] = 0u; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+                if (j == 1u && (w & 4u) != 0u) ok[0] &= ~kBack;
+                if (j == 2u) { ok[0] &= kBack; ok[1] = 0u; ok[2] = 0u; ok[3] = 0u; }
+                uint32_t pa;
+                unsigned long long pm;
+                windows_lds<K>(ch, lb.C, ok, hist_base, pa, pm);
+            }
+        }
+#endif
         if constexpr (INDEX) {
             anchors = nanch;
             const uint32_t tot = lane_bcast(wave_inclusive_sum(nsite), 63);

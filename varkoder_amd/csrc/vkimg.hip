@@ -234,8 +234,10 @@ int launch_count(vk_ctx* ctx, const uint8_t* d_fastq, const uint64_t* d_offs, co
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_wavephase, atomic_flush, ctx->d_aside,
                                static_cast<uint32_t>(cap), d_aside_n, IndexParams{});
             VK_HIP(ctx, hipGetLastError());
+#ifndef VK_DIAG_ASIDE_INLINE   // (diagnostic: the count kernel counts its own lists, vk_count.h)
             hipLaunchKernelGGL((vk_aside_kernel<K, false>), dim3(nsamples * ablocks), dim3(kCountThreads), 0, ctx->stream, d_fastq,
                                d_offs, d_lens, nsamples, parts, d_hist, ctx->d_aside, static_cast<uint32_t>(cap), d_aside_n, IndexParams{}, upb);
+#endif
         }
     }
     VK_HIP(ctx, hipGetLastError());

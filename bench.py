@@ -798,6 +798,7 @@ class ClockSampler:
     def __init__(self, device_index):
         import threading
         self.path, self.err, self.vals, self.stop_flag, self.thread = None, None, [], threading.Event(), None
+        self.marked = False    # samples count from mark() on: the timed steps
         try:
             import glob
             import torch
@@ -818,6 +819,9 @@ class ClockSampler:
                     return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
         return None
 
+    def mark(self):
+        self.marked = True
+
     def start(self):
         if self.path is None:
             return
@@ -827,7 +831,7 @@ class ClockSampler:
             while not self.stop_flag.is_set():
                 try:
                     v = self.read()
-                    if v:
+                    if v and self.marked:
                         self.vals.append(v)
                 except Exception as e:  # noqa: BLE001
                     self.err = repr(e)
@@ -971,6 +975,8 @@ def main():
         if e:
             e[2].record()
 
+    clocks = ClockSampler(local_rank)      # (a host thread reading one sysfs file every 10 ms: nothing on the GPU's side)
+    clocks.start()
     for _ in range(args.warmup):
         step()
 
@@ -980,8 +986,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    clocks = ClockSampler(local_rank)      # (a host thread reading one sysfs file every 10 ms: nothing on the GPU's side)
-    clocks.start()
+    clocks.mark()     # (the thread has been running since before the warm-up: nothing between the fence and the first step)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(ev[i])

@@ -57,6 +57,20 @@ for name, x in (("lifetime of a wavefront (ms)", dur / 1e3), ("finishes at (ms)"
                 ("tokens per round", v[:, 3] / np.maximum(v[:, 2], 1))):
     q = np.percentile(x, [0, 10, 50, 90, 99, 100])
     print(f"{name:32s} min {q[0]:10.1f}  p10 {q[1]:10.1f}  median {q[2]:10.1f}  p90 {q[3]:10.1f}  p99 {q[4]:10.1f}  max {q[5]:10.1f}  mean {x.mean():10.1f}")
+# what a wavefront's lifetime goes with: its own work (tokens, cycles it counted itself), or the company it keeps
+own = v[:, 4:8].sum(axis=1)
+print("lifetime against the wavefront's own work: correlation with tokens %.3f, with its own counted cycles %.3f" %
+      (np.corrcoef(dur, v[:, 3])[0, 1], np.corrcoef(dur, own)[0, 1]))
+share = own / np.maximum(dur * 1e-6 * 2.1e9, 1)   # counted cycles / wall cycles at ~2.1 GHz
+q = np.percentile(share, [0, 10, 50, 90, 100])
+print("counted cycles / lifetime (the share of the wall clock the wavefront was in its stamped sections, incl. waits): "
+      "min %.2f p10 %.2f median %.2f p90 %.2f max %.2f" % tuple(q))
+order = np.argsort(v[:, 0])
+k = len(order) // 8
+for part in range(8):
+    sel = order[part * k:(part + 1) * k]
+    print("  started %5.2f-%5.2f ms: lifetime mean %6.1f ms, tokens mean %8.0f, own cycles mean %6.1f M" %
+          ((v[sel, 0].min() - t0) / 1e5, (v[sel, 0].max() - t0) / 1e5, dur[sel].mean() / 1e3, v[sel, 3].mean(), own[sel].mean() / 1e6))
 tot = v[:, 4:8].sum()
 for name, col in (("gz_tokens", 4), ("gz_resolve", 6), ("headers + tables", 7)):
     print(f"{name:20s} {100 * v[:, col].sum() / tot:5.1f} %   {v[:, col].sum() / max(v[:, 3].sum(), 1):9.1f} cycles per token")

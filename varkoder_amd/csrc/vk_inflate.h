@@ -819,7 +819,8 @@ template <bool SYM>
 __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in, uint64_t nbytes, uint8_t* out8, uint16_t* out16,
                         uint64_t cap, uint64_t start_bit, bool at_header, const uint64_t* starts, uint32_t my_chunk,
                         uint32_t nchunks, uint64_t& out_len, uint32_t& out_status, uint32_t& out_next,
-                        uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc, uint2* memrec) {
+                        uint64_t& out_endbit, uint32_t& out_isize_sum, uint32_t& out_members, uint32_t& out_crc, uint2* memrec,
+                        uint32_t span_bits = 0) {   // span_bits: the compressed bits this wavefront is expected to decode (a chunk's; 0: not told)
     const int lane = threadIdx.x & 63;
     const uint64_t nbits = nbytes * 8;
 #ifdef VK_GZ_STAMPS
@@ -868,6 +869,29 @@ __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in
         GZ_T(r1);
         acc_res += r1 - r0;
         n_rounds += gz_uni(r.rounds);
+#endif
+    };
+
+    // ---- pacing ------------------------------------------------------------------------------------
+    // A SIMD issues for its OLDEST ready wavefront first.  The chunk decoder's wavefronts all start together, hold one chunk
+    // each and never leave before it is done: the oldest got the issue slots and finished after 43 ms, the youngest after 66
+    // (equal work: tools/gz_stamps.py), and for the last third of the launch a SIMD was left with one or two wavefronts that
+    // cannot fill it on their own (the launch: 73 ms for wavefronts that live 52 on average).  So a wavefront that is BEHIND
+    // asks for priority (s_setprio outranks age): by how far into its chunk it is -- under a half 3, under three quarters 2,
+    // under nine tenths 1, then 0 -- set anew at every block start.  The launch: 73 -> 64 ms, the call -9 %.  (Coarse on
+    // purpose.  A build that kept every wavefront within 1.6 % of the launch's mean progress -- two words in memory, a
+    // returning atomic every fourth ring -- made them arrive within 6 % of one another and took 88 ms: wavefronts held in
+    // step are in the resolver together and in gz_tokens together, and it is the mix of the two on a SIMD that fills it.)
+    auto pace = [&]() {
+#ifndef VK_GZ_NO_PRIO
+        if (!SYM || span_bits == 0u) return;
+        const uint64_t d = pos - start_bit;
+        const uint32_t unit = (span_bits >> 7) ? (span_bits >> 7) : 1u;
+        const uint32_t at = gz_uni(d >= span_bits ? 128u : static_cast<uint32_t>(d) / unit);   // 1/128ths of the chunk
+        if (at < 64u) __builtin_amdgcn_s_setprio(3);
+        else if (at < 96u) __builtin_amdgcn_s_setprio(2);
+        else if (at < 116u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
 #endif
     };
 
@@ -921,6 +945,7 @@ __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in
         bool last = false;
         while (!last && st == 0) {
             if (pos + 3 > nbits) { st |= kGzTruncated; break; }
+            pace();
             GZ_T(ta);
             uint64_t w = gz_peek(in, nbytes, pos);
             last = (w & 1u) != 0u;
@@ -1229,7 +1254,8 @@ __global__ __launch_bounds__(64, VK_GZ_CHUNK_OCC) void vk_gzchunk_kernel(const u
         st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
     } else {
         gz_wave<true>(L, hist, gz + ch.in_off, ch.in_len, nullptr, sym + ch.out_off, ch.out_cap, s0, j == 0,
-                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr, memrec + static_cast<size_t>(c) * kGzMemRec);
+                      starts + ch.file_chunk0, j, ch.nchunks, n, st, nx, eb, isum, nm, cr, memrec + static_cast<size_t>(c) * kGzMemRec,
+                      ch.chunk_bytes * 8u);
     }
     if ((threadIdx.x & 63) == 0) {
         out_len[c] = n;

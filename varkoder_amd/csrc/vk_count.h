@@ -1370,7 +1370,19 @@ __global__ __launch_bounds__(kCountThreads, VK_K1_OCC) void vk_count_dense_kerne
         unsigned long long st_wait = 0, st_all = 0, st_t0 = 0, st_t1 = 0, st_prev = 0;
         VK_STAMP(st_prev);
 #endif
+#ifndef VK_DIAG_K1_NO_PACE
+        const uint32_t pace_at = npieces - (npieces >> 2);   // (>= 1: the first piece of a range of under four runs at 1 too)
+        __builtin_amdgcn_s_setprio(1);
+#endif
         for (uint32_t it = 0; it < npieces; ++it) {
+#ifndef VK_DIAG_K1_NO_PACE
+            // A SIMD issues for its oldest ready wavefront first, and of a workgroup's four wavefronts on a SIMD the same one is
+            // always the oldest: equal ranges ended apart, and a wave slot whose wavefront is done waits for the workgroup's last
+            // (the inflate chunk decoder, vk_inflate.h, showed the effect at its largest).  The first three quarters of a range
+            // run at priority 1, the last at 0: who is behind passes who is ahead.  -1 % (60.7 -> 60.0 ms; four levels the same,
+            // the levels the other way round nothing: profiles/ab/r06_inflate_pacing.txt).
+            if (it == pace_at) __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef VK_STAMPS
             VK_STAMP(st_t0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

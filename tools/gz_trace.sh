@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 LEVEL=$1; shift
 for lib in "$@"; do
   tag=$(basename "$lib" .so)
-  OUT=gpurun_out/r05/gztrace_$tag
+  OUT=gpurun_out/gztrace/$tag
   mkdir -p $OUT
   if [ "$lib" = "default" ]; then unset VKIMG_LIB; else export VKIMG_LIB=$lib; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 tools/inflate_time.py 64 400000 $LEVEL > $OUT/out.txt 2>&1

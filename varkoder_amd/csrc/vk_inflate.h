@@ -1318,9 +1318,11 @@ __global__ __launch_bounds__(256) void vk_gzfinal_kernel(const uint16_t* __restr
         const uint32_t x = e[i];
         out[i] = static_cast<uint8_t>(x < 0x8000u ? x : w[x & 0x7FFFu]);
     };
-    // eight elements per thread where the text is 8-byte aligned (16 bytes in, 8 bytes out); the few before and
-    // after that by the first threads of block 0
-    const uint64_t head = (8u - (reinterpret_cast<uint64_t>(out) & 7u)) & 7u;
+    // eight elements per thread from where the ELEMENTS are 16-byte aligned (16 bytes in, 8 bytes out); the few before and
+    // after that by the first threads of block 0.  (The 16-byte loads want their alignment more than the 8-byte stores
+    // theirs: with the text aligned instead the kernel took 8.4 ms for 64 files of 128 MB, so 7.6; sixteen elements per
+    // thread, non-temporal accesses, a contiguous span per workgroup: nothing.)
+    const uint64_t head = ((16u - (reinterpret_cast<uint64_t>(e) & 15u)) & 15u) >> 1;
     const uint64_t h = head < it.len ? head : it.len;
     const uint64_t groups = (it.len - h) / 8, tail0 = h + groups * 8;
     if (blockIdx.x == 0) {
@@ -1346,7 +1348,7 @@ __global__ __launch_bounds__(256) void vk_gzfinal_kernel(const uint16_t* __restr
         uint2 o;
         o.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
         o.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        *reinterpret_cast<uint2*>(out + i) = o;
+        __builtin_memcpy(out + i, &o, 8);   // (wherever it falls)
     }
 }
 

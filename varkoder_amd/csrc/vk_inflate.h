@@ -405,6 +405,8 @@ struct GzChunk {
     uint32_t pad_;
 };
 constexpr uint64_t kGzNone = ~0ull;       // start_bit of a chunk in which no block start was found
+constexpr uint64_t kGzPending = 0xFEFEFEFEFEFEFEFEull;   // ... of a chunk whose wavefront has not looked yet (the host's memset; vk_gzchunk_kernel)
+constexpr uint32_t kGzSpinMax = 1u << 15;  // looks at a pending start before it is given up as "none" (~2 us apart: 60 ms -- the wavefront next door needs 13 at most)
 constexpr uint32_t kGzEnd = 0xFFFFFFFFu;  // next[] of the chunk that decoded the file's last member
 constexpr uint32_t kGzMemRec = 62;         // member trailers a wavefront records (end of the member's text in ITS output, CRC-32 word); a file with more in one chunk goes unchecked
 
@@ -872,6 +874,25 @@ __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in
 #endif
     };
 
+    // The block start of chunk jj of this file.  The chunks' wavefronts find their own starts (vk_gzchunk_kernel) and publish
+    // them; one that has not looked yet (the first chunk of the next round of the launch, when this wavefront is the last of
+    // its own) is waited for -- briefly, and not for ever: what is still pending after kGzSpinMax looks counts as "none",
+    // this wavefront decodes on through that chunk, whose own output is then never linked (exact; slower).
+    uint32_t known_jj = 0xFFFFFFFFu;
+    uint64_t known_start = 0;
+    auto start_at = [&](uint32_t jj) -> uint64_t {
+        if (jj == known_jj) return known_start;
+        uint64_t v = __hip_atomic_load(starts + jj, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t look = 0; gz_uni64(v) == kGzPending && look < kGzSpinMax; ++look) {
+            __builtin_amdgcn_s_sleep(64);
+            v = __hip_atomic_load(starts + jj, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        v = gz_uni64(v);
+        known_jj = jj;
+        known_start = v == kGzPending ? kGzNone : v;
+        return known_start;
+    };
+
     // ---- pacing ------------------------------------------------------------------------------------
     // A SIMD issues for its OLDEST ready wavefront first.  The chunk decoder's wavefronts all start together, hold one chunk
     // each and never leave before it is done: the oldest got the issue slots and finished after 43 ms, the youngest after 66
@@ -1012,8 +1033,8 @@ __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in
             }
             // a block has ended at `pos`: in a chunk, stop where a later chunk begins
             if (SYM && !last) {
-                while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;  // starts inside what was decoded: not block starts after all
-                if (jn < nchunks && starts[jn] == pos) {
+                while (jn < nchunks && (start_at(jn) == kGzNone || start_at(jn) < pos)) ++jn;  // starts inside what was decoded: not block starts after all
+                if (jn < nchunks && start_at(jn) == pos) {
                     next = jn;
                     stop = true;
                     break;
@@ -1037,7 +1058,7 @@ __device__ void gz_wave(GzLds& L, uint16_t* hist, const uint8_t* __restrict__ in
         ++members;
         pos = (b + 8) * 8;
         if (SYM) {  // the starts found inside what this chunk decoded (none, or false ones) are behind us
-            while (jn < nchunks && (starts[jn] == kGzNone || starts[jn] < pos)) ++jn;
+            while (jn < nchunks && (start_at(jn) == kGzNone || start_at(jn) < pos)) ++jn;
         }
     }
     if (st == 0 && stop) resolve();
@@ -1100,18 +1121,12 @@ constexpr uint32_t kGzBigFile = 1u << 19;                             // files a
 constexpr uint32_t kGzChunkLds = static_cast<uint32_t>(sizeof(GzLds)) + 2u * kGzHist;
 constexpr uint32_t kGzChunkWaves = (160u * 1024u / kGzChunkLds) < 4u * VK_GZ_CHUNK_OCC ? (160u * 1024u / kGzChunkLds) : 4u * VK_GZ_CHUNK_OCC;   // wavefronts of vk_gzchunk_kernel a CU holds (LDS, registers)
 
-__global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
-                                                        uint32_t nchunks_total, uint64_t* __restrict__ starts) {
-    __shared__ GzLds L;
-    const uint32_t c = blockIdx.x;
-    if (c >= nchunks_total) return;
-    const GzChunk ch = chunks[c];
+// The block start of chunk `c` (step (1) above): bit position in the file, 0 for a file's first chunk, kGzNone when the
+// chunk holds none.  The whole wavefront; wave-uniform result.
+__device__ __forceinline__ uint64_t gz_find_start(GzLds& L, const uint8_t* __restrict__ gz, const GzChunk& ch, uint32_t c) {
     const int lane = threadIdx.x & 63;
     const uint32_t j = c - ch.file_chunk0;
-    if (j == 0) {  // the file's first chunk starts at the gzip header
-        if (lane == 0) starts[c] = 0;
-        return;
-    }
+    if (j == 0) return 0;  // the file's first chunk starts at the gzip header
     const uint8_t* in = gz + ch.in_off;
     const uint64_t nbytes = ch.in_len, nbits = nbytes * 8;
     const uint64_t from = static_cast<uint64_t>(j) * ch.chunk_bytes * 8;
@@ -1231,16 +1246,27 @@ __global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restr
         g_gz_find[c][4] = n_slow; g_gz_find[c][5] = acc_slow; g_gz_find[c][6] = max_full; g_gz_find[c][7] = n_iter;
     }
 #endif
-    if (lane == 0) starts[c] = found;
+    return found;
+}
+
+// (1) as a launch of its own (VKIMG_GZ_SPLIT_FIND=1; tests, A/B timing): vk_gzchunk_kernel finds its chunks' starts itself.
+__global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restrict__ gz, const GzChunk* __restrict__ chunks,
+                                                        uint32_t nchunks_total, uint64_t* __restrict__ starts) {
+    __shared__ GzLds L;
+    const uint32_t c = blockIdx.x;
+    if (c >= nchunks_total) return;
+    const GzChunk ch = chunks[c];
+    const uint64_t found = gz_find_start(L, gz, ch, c);
+    if ((threadIdx.x & 63) == 0) starts[c] = found;
 }
 
 __global__ __launch_bounds__(64, VK_GZ_CHUNK_OCC) void vk_gzchunk_kernel(const uint8_t* __restrict__ gz, uint16_t* __restrict__ sym,
                                                          const GzChunk* __restrict__ chunks, uint32_t nchunks_total,
-                                                         const uint64_t* __restrict__ starts,
+                                                         uint64_t* starts,   // (fused: every entry kGzPending at launch, written by its chunk's wavefront, read by others)
                                                          unsigned long long* __restrict__ out_len, uint32_t* __restrict__ status,
                                                          uint32_t* __restrict__ next, uint32_t* __restrict__ isize_sum,
                                                          uint32_t* __restrict__ members, uint32_t* __restrict__ crc,
-                                                         uint2* __restrict__ memrec) {
+                                                         uint2* __restrict__ memrec, uint32_t fused) {
     __shared__ GzLds L;
     __shared__ uint16_t hist[kGzHist];
     const uint32_t c = blockIdx.x;
@@ -1249,7 +1275,19 @@ __global__ __launch_bounds__(64, VK_GZ_CHUNK_OCC) void vk_gzchunk_kernel(const u
     const uint32_t j = c - ch.file_chunk0;
     uint64_t n = 0, eb = 0;
     uint32_t st = 0, nx = kGzEnd, isum = 0, nm = 0, cr = 0;
-    const uint64_t s0 = starts[c];
+    uint64_t s0;
+    if (fused) {
+        // Step (1) here, not in a launch of its own: that launch lasted as long as its slowest chunk (12.7 ms for a mean of
+        // 6.5 per chunk); a wavefront that has its start decodes at once.  At the top priority: the decoders next to it on
+        // the SIMD ask for theirs by their progress (gz_wave), and another chunk's wavefront may be waiting for this start.
+        __builtin_amdgcn_s_setprio(3);
+        s0 = gz_uni64(gz_find_start(L, gz, ch, c));
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(starts + c, s0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (L is handed from the finder to the decoder)
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        s0 = starts[c];
+    }
     if (s0 == kGzNone) {
         st = 0x80000000u;  // no block start in this chunk: the chunk before decodes through it
     } else {

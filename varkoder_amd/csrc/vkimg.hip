@@ -98,6 +98,7 @@ struct vk_ctx {
     size_t gzcrc_cap = 0;
     bool gz_no_chunks = false;    // VKIMG_GZ_NO_CHUNKS=1: every file through the one-wavefront kernel (tests, A/B timing)
     uint32_t gz_chunk_bytes = 0;  // VKIMG_GZ_CHUNK_BYTES: fixed chunk size of the chunked inflate (0 = fitted to the device)
+    bool gz_split_find = false;   // VKIMG_GZ_SPLIT_FIND=1: the chunks' block starts by a launch of its own (vk_gzfind_kernel; rounds 2-5) instead of by the chunk decoder's wavefronts themselves (tests, A/B timing)
     uint32_t gz_lds_pad = 0;      // VKIMG_GZ_LDS_PAD: bytes of LDS a chunk wavefront asks for on top of its own (A/B timing: fewer wavefronts per CU)
     int num_cus = 256;
     size_t sub_cap = 0;
@@ -522,6 +523,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         ctx->gz_no_chunks = g && g[0] == '1';
         const char* cb = getenv("VKIMG_GZ_CHUNK_BYTES");
         if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
+        const char* sf = getenv("VKIMG_GZ_SPLIT_FIND");
+        ctx->gz_split_find = sf && sf[0] == '1';
         const char* lp = getenv("VKIMG_GZ_LDS_PAD");
         if (lp && lp[0]) ctx->gz_lds_pad = static_cast<uint32_t>(strtoul(lp, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
@@ -1212,10 +1215,14 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         uint2* d_rec = reinterpret_cast<uint2*>(m + o_rec);
         uint16_t* d_sym = reinterpret_cast<uint16_t*>(ctx->d_gzsym);
         VK_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), nc * sizeof(GzChunk), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(vk_gzfind_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_chunks, nc, d_starts);
-        VK_HIP(ctx, hipGetLastError());
+        if (ctx->gz_split_find) {
+            hipLaunchKernelGGL(vk_gzfind_kernel, dim3(nc), dim3(64), 0, ctx->stream, gz, d_chunks, nc, d_starts);
+            VK_HIP(ctx, hipGetLastError());
+        } else {
+            VK_HIP(ctx, hipMemsetAsync(d_starts, 0xFE, nc * 8ull, ctx->stream));   // kGzPending: the chunks' wavefronts find their own starts
+        }
         hipLaunchKernelGGL(vk_gzchunk_kernel, dim3(nc), dim3(64), ctx->gz_lds_pad, ctx->stream, gz, d_sym, d_chunks, nc, d_starts, d_len,
-                           d_st, d_next, d_is, d_nm, d_cr, d_rec);
+                           d_st, d_next, d_is, d_nm, d_cr, d_rec, ctx->gz_split_find ? 0u : 1u);
         VK_HIP(ctx, hipGetLastError());
         std::vector<unsigned long long> h_len(nc);
         std::vector<uint32_t> h_st(nc), h_next(nc), h_is(nc), h_nm(nc), h_cr(nc);

@@ -1171,12 +1171,29 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         // Chunk size: 128 KiB gives a small call the most wavefronts (8 files of 24 MB: 48 ms against 72 ms with
         // 256 KiB); once there are more chunks than the device holds wavefronts, throughput no longer
         // depends on it (measured flat from 128 to 320 KiB) and 256 KiB halves the per-chunk work of the finder.
+        // Round 6: the chunk decoder's wavefronts are all resident from the start when there are no more of them than the device
+        // holds (slots), and a launch of 1.26 rounds is the worst there is (64 files of 24 MB, level 1: 96.9 ms at 192 KiB = 1.26
+        // rounds, 88.0 at 128 KiB = 1.9, 80.9 at 256 KiB = 0.95, 86.4 at 320 KiB = 0.76): the size is fitted so that the chunks
+        // fill 0.96 of the slots a whole number of times, the fewest times that keep a chunk under 352 KiB.
         uint32_t chunk_bytes = ctx->gz_chunk_bytes;
         if (chunk_bytes == 0) {
             uint64_t big_total = 0;
             for (uint32_t i : big) big_total += gz_lengths[i];
             const uint64_t slots = static_cast<uint64_t>(ctx->num_cus) * kGzChunkWaves;
-            chunk_bytes = big_total / kGzChunkMin > slots ? 2 * kGzChunkMin : kGzChunkMin;
+            chunk_bytes = kGzChunkMin;
+            if (big_total / kGzChunkMin > slots) {
+                for (uint64_t rounds = 1; rounds <= 64; ++rounds) {
+                    // (every file ends in a part of a chunk: half a chunk per file goes off the count)
+                    const double want = 0.96 * static_cast<double>(slots * rounds) - 0.5 * static_cast<double>(big.size());
+                    if (want < 1.0) continue;
+                    const uint64_t cb = (static_cast<uint64_t>(static_cast<double>(big_total) / want) + 4095u) & ~4095ull;
+                    if (cb <= 352u * 1024u) {
+                        chunk_bytes = cb < kGzChunkMin ? kGzChunkMin : static_cast<uint32_t>(cb);
+                        break;
+                    }
+                    chunk_bytes = 2 * kGzChunkMin;   // (never reached by a sane input: a thousand rounds)
+                }
+            }
         }
         if (chunk_bytes < 65536u) chunk_bytes = 65536u;
         for (size_t b = 0; b < big.size(); ++b) {

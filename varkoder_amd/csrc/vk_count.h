@@ -624,7 +624,15 @@ __device__ __forceinline__ void wave_stream(const uint8_t* __restrict__ sbase_, 
 #ifdef VK_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, acc[4] = {0, 0, 0, 0};
 #endif
+#ifndef VK_DIAG_K1_NO_PACE   // (the dense kernel's two priority levels, see there: the last quarter of a range at the lower one.  k = 9 pass A:
+    // 12.70 / 12.43 -> 12.45 / 12.42 ms on uniform reads, 13.50 -> 13.40 GC-skewed, 14.18 -> 13.97 fastp-shaped, alternating runs of one call)
+    const uint32_t pace_at = npieces - (npieces >> 2);
+    __builtin_amdgcn_s_setprio(1);
+#endif
     for (uint32_t it = 0; it < npieces; ++it) {
+#ifndef VK_DIAG_K1_NO_PACE
+        if (it == pace_at) __builtin_amdgcn_s_setprio(0);
+#endif
         VK_STAMP(t0);
         if (PF == 0) load_piece(it);
         if (it + 1 == npieces && (tail_bytes & 15u) != 0u) {  // wave-uniform, once per range at most

@@ -99,6 +99,7 @@ struct vk_ctx {
     bool gz_no_chunks = false;    // VKIMG_GZ_NO_CHUNKS=1: every file through the one-wavefront kernel (tests, A/B timing)
     uint32_t gz_chunk_bytes = 0;  // VKIMG_GZ_CHUNK_BYTES: fixed chunk size of the chunked inflate (0 = fitted to the device)
     bool gz_split_find = false;   // VKIMG_GZ_SPLIT_FIND=1: the chunks' block starts by a launch of its own (vk_gzfind_kernel; rounds 2-5) instead of by the chunk decoder's wavefronts themselves (tests, A/B timing)
+    uint32_t gz_fill_pct = 0;     // VKIMG_GZ_FILL: per cent of the device's chunk-wavefront slots a round of chunks is fitted to (0 = 99; A/B timing)
     uint32_t gz_lds_pad = 0;      // VKIMG_GZ_LDS_PAD: bytes of LDS a chunk wavefront asks for on top of its own (A/B timing: fewer wavefronts per CU)
     int num_cus = 256;
     size_t sub_cap = 0;
@@ -525,6 +526,8 @@ int vk_ctx_create(int device, void* stream, int own_stream, vk_ctx** out) {
         if (cb && cb[0]) ctx->gz_chunk_bytes = static_cast<uint32_t>(strtoul(cb, nullptr, 10));
         const char* sf = getenv("VKIMG_GZ_SPLIT_FIND");
         ctx->gz_split_find = sf && sf[0] == '1';
+        const char* fp = getenv("VKIMG_GZ_FILL");
+        if (fp && fp[0]) ctx->gz_fill_pct = static_cast<uint32_t>(strtoul(fp, nullptr, 10));
         const char* lp = getenv("VKIMG_GZ_LDS_PAD");
         if (lp && lp[0]) ctx->gz_lds_pad = static_cast<uint32_t>(strtoul(lp, nullptr, 10));
         const char* r = getenv("VKIMG_SPILL_RUNS_CAP");
@@ -1174,7 +1177,9 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
         // Round 6: the chunk decoder's wavefronts are all resident from the start when there are no more of them than the device
         // holds (slots), and a launch of 1.26 rounds is the worst there is (64 files of 24 MB, level 1: 96.9 ms at 192 KiB = 1.26
         // rounds, 88.0 at 128 KiB = 1.9, 80.9 at 256 KiB = 0.95, 86.4 at 320 KiB = 0.76): the size is fitted so that the chunks
-        // fill 0.96 of the slots a whole number of times, the fewest times that keep a chunk under 352 KiB.
+        // fill 0.99 of the slots a whole number of times, the fewest times that keep a chunk under 352 KiB -- by the exact count
+        // (every file's length is known), so that a SIMD holds six wavefronts or, here and there, five: at 0.96 a quarter of the
+        // SIMDs held five and were done a sixth early (64 files of 33 MB: 113.5 ms at 0.96, 102.1 at 0.99 and at 1.00; 0.90: 115.9).
         uint32_t chunk_bytes = ctx->gz_chunk_bytes;
         if (chunk_bytes == 0) {
             uint64_t big_total = 0;
@@ -1184,9 +1189,18 @@ int vk_inflate_device(vk_ctx* ctx, const void* d_gz, const uint64_t* gz_offsets,
             if (big_total / kGzChunkMin > slots) {
                 for (uint64_t rounds = 1; rounds <= 64; ++rounds) {
                     // (every file ends in a part of a chunk: half a chunk per file goes off the count)
-                    const double want = 0.96 * static_cast<double>(slots * rounds) - 0.5 * static_cast<double>(big.size());
+                    const double fill = ctx->gz_fill_pct ? 0.01 * ctx->gz_fill_pct : 0.99;
+                    const double want = fill * static_cast<double>(slots * rounds) - 0.5 * static_cast<double>(big.size());
                     if (want < 1.0) continue;
-                    const uint64_t cb = (static_cast<uint64_t>(static_cast<double>(big_total) / want) + 4095u) & ~4095ull;
+                    uint64_t cb = (static_cast<uint64_t>(static_cast<double>(big_total) / want) + 4095u) & ~4095ull;
+                    if (cb < kGzChunkMin) cb = kGzChunkMin;
+                    // (the count is known exactly: never one chunk more than the rounds hold)
+                    for (;;) {
+                        uint64_t count = 0;
+                        for (uint32_t i : big) count += (gz_lengths[i] + cb - 1) / cb;
+                        if (count <= static_cast<uint64_t>(fill * static_cast<double>(slots * rounds)) || cb > 352u * 1024u) break;
+                        cb += 4096;
+                    }
                     if (cb <= 352u * 1024u) {
                         chunk_bytes = cb < kGzChunkMin ? kGzChunkMin : static_cast<uint32_t>(cb);
                         break;

@@ -419,3 +419,16 @@ def test_giant_sample_over_two_ranks_through_the_kernel():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert st == 0 and np.array_equal(total, want)
+
+
+def test_without_a_tail_weightless_files_stay_in_the_static_deal():
+    """tail_frac = 0 (ranks without a process group: each has only a local cursor): nothing may land in the tail, not
+    even files of weight 0 (missing or empty ones) -- every rank would claim all of them from its own cursor."""
+    from varkoder_amd import shard
+    weights = [500, 0, 300, 0, 200]
+    head, tail = shard.split_head_tail(weights, 0.0)
+    assert tail == [] and head == [0, 2, 4, 1, 3]
+    dealt = [sorted(head[j] for j in shard.shard_by_size([weights[i] for i in head], r, 2)) for r in range(2)]
+    assert sorted(dealt[0] + dealt[1]) == list(range(5))
+    head, tail = shard.split_head_tail(weights, 0.1)      # with a tail, the weightless ones are its first members
+    assert sorted(head + tail) == list(range(5)) and set(tail) >= {1, 3}

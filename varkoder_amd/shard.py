@@ -95,6 +95,8 @@ def split_head_tail(weights, tail_frac=0.1):
     commands/image.py:1281-1284): a static deal balances ESTIMATES (a .gz's text bytes, a k = 9 count whose time
     depends on the bases), the tail absorbs what the estimates got wrong."""
     order = sorted(range(len(weights)), key=lambda i: (-int(weights[i]), i))
+    if tail_frac <= 0:   # (no tail asked for: weightless items -- missing or empty files -- stay in the static deal too)
+        return order, []
     total = sum(int(w) for w in weights)
     left, cut = total, len(order)
     for n, i in enumerate(order):

@@ -39,6 +39,9 @@ constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindBad = 3;
 constexpr uint32_t kKindLong = 4;  // (in registers only) a code longer than a table's root: that token is decoded on the side
 constexpr uint32_t kBadEntry = kKindBad << 4;
 
+#ifndef VK_GZ_SYMTAB
+#define VK_GZ_SYMTAB 1   // base value and extra bits of a length / distance symbol from two small LDS tables (96 bytes) instead of arithmetic: -12 vector instructions in gz_tokens, 78.2 -> 76.2 / 71.2 -> 69.2 ms at zlib levels 1 / 6 (profiles/ab/r06_gz_symtab.txt); 0: round 5's arithmetic
+#endif
 struct GzLds {
     uint16_t lit[1 << kLitRoot];
     uint16_t dst[1 << kDistRoot];
@@ -46,6 +49,12 @@ struct GzLds {
     uint16_t lit_sym[288];       // symbols ordered by (code length, symbol): canonical decoding of long codes
     uint16_t dst_sym[32];
     uint16_t lit_cnt[16], dst_cnt[16];
+#if VK_GZ_SYMTAB
+    // base = (m << extra) + 3 for a length symbol, (m << extra) + 1 for a distance symbol (gz_lds_init); 96 bytes: the
+    // wavefront's LDS stays inside its five 1280-byte allocation granules (6272 + 96 <= 6400), see kGzChunkLds
+    uint16_t len_tab[32];        // m | extra << 8
+    uint8_t dist_tab[32];        // m | extra << 2
+#endif
     union {
         uint8_t lens[320];       // block set-up: code lengths
         uint32_t start[64];      // resolver: output offsets of the 64 tokens in hand
@@ -80,6 +89,22 @@ __device__ __forceinline__ void gz_dist_of(uint32_t s, uint32_t& base, uint32_t&
         base = ((2u + (s & 1u)) << extra) + 1u;
     }
 }
+
+#if VK_GZ_SYMTAB
+template <typename LdsT>
+__device__ __forceinline__ void gz_lds_init(LdsT& L) {
+    const uint32_t i = threadIdx.x & 63u;
+    if (i < 32u) {
+        uint32_t b, x;
+        gz_len_of(i < 29u ? i : 0u, b, x);
+        L.len_tab[i] = static_cast<uint16_t>(((b - 3u) >> x) | (x << 8));
+        gz_dist_of(i < 30u ? i : 0u, b, x);
+        L.dist_tab[i] = static_cast<uint8_t>(((b - 1u) >> x) | (x << 2));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+}
+#endif
 
 // entry of a literal/length symbol (0..285; 286, 287 are invalid) without its code length
 __device__ __forceinline__ uint32_t gz_lit_entry(uint32_t s) {
@@ -485,13 +510,29 @@ __device__ __attribute__((noinline)) GzRun gz_tokens(GzLdsP L, const uint8_t* in
         const uint32_t lused = e & 15u;
         const uint32_t lkind = (e >> 4) & 3u;
         uint32_t lbase, xb;
+#if VK_GZ_SYMTAB
+        {
+            const uint32_t lt = L->len_tab[(e >> 6) & 31u];
+            xb = lt >> 8;
+            lbase = ((lt & 255u) << xb) + 3u;
+        }
+#else
         gz_len_of((e >> 6) & 31u, lbase, xb);
+#endif
         const uint32_t len = lbase + (static_cast<uint32_t>(ww >> lused) & ((1u << xb) - 1u));
         const uint64_t w2 = ww >> (lused + xb);
         const uint32_t d = L->dst[static_cast<uint32_t>(w2) & ((1u << kDistRoot) - 1u)];
         const uint32_t dl = d & 15u;
         uint32_t dbase, dxb;
+#if VK_GZ_SYMTAB
+        {
+            const uint32_t dt = L->dist_tab[(d >> 6) & 31u];
+            dxb = dt >> 2;
+            dbase = ((dt & 3u) << dxb) + 1u;
+        }
+#else
         gz_dist_of((d >> 6) & 31u, dbase, dxb);
+#endif
         const uint32_t dist = dbase + (static_cast<uint32_t>(w2 >> dl) & ((1u << dxb) - 1u));
         const bool is_len = lkind == kKindLen;
         const bool longc = lused == 15u || (is_len && dl == 15u);
@@ -1087,6 +1128,9 @@ __global__ __launch_bounds__(64) void vk_inflate_kernel(const uint8_t* __restric
     __shared__ uint16_t hist[kGzHist];
     const uint32_t job = blockIdx.x;
     if (job >= njobs) return;
+#if VK_GZ_SYMTAB
+    gz_lds_init(L);
+#endif
     uint64_t n = 0, endbit = 0;
     uint32_t st = 0, next = 0, isum = 0, nm = 0, cr = 0;
     gz_wave<false>(L, hist, gz + jobs[job].in_off, jobs[job].in_len, out + jobs[job].out_off, nullptr, jobs[job].out_cap, 0, true,
@@ -1118,8 +1162,15 @@ constexpr uint32_t kGzBigFile = 1u << 19;                             // files a
 #ifndef VK_GZ_CHUNK_OCC
 #define VK_GZ_CHUNK_OCC 6     // wavefronts of vk_gzchunk_kernel per SIMD the register budget is set for
 #endif
+// A workgroup's LDS is allocated in granules of 1280 bytes on this part (160 KiB = 128 of them), measured, not read: 192 bytes
+// of padding in GzLds (6272 -> 6464 bytes: five granules -> six, 25 -> 21 wavefronts per CU where the register budget asks for
+// 24) turned 78.0 ms into 108.2 -- the chunks are fitted to ONE round of the slots counted here, and the wavefronts that did not
+// fit ran as a second one (profiles/ab/r06_gz_symtab.txt).  So the count is by granules, and growing GzLds past five is an error.
+constexpr uint32_t kLdsGranule = 1280;
 constexpr uint32_t kGzChunkLds = static_cast<uint32_t>(sizeof(GzLds)) + 2u * kGzHist;
-constexpr uint32_t kGzChunkWaves = (160u * 1024u / kGzChunkLds) < 4u * VK_GZ_CHUNK_OCC ? (160u * 1024u / kGzChunkLds) : 4u * VK_GZ_CHUNK_OCC;   // wavefronts of vk_gzchunk_kernel a CU holds (LDS, registers)
+constexpr uint32_t kGzChunkLdsAlloc = (kGzChunkLds + kLdsGranule - 1u) / kLdsGranule * kLdsGranule;
+constexpr uint32_t kGzChunkWaves = (160u * 1024u / kGzChunkLdsAlloc) < 4u * VK_GZ_CHUNK_OCC ? (160u * 1024u / kGzChunkLdsAlloc) : 4u * VK_GZ_CHUNK_OCC;   // wavefronts of vk_gzchunk_kernel a CU holds (LDS, registers)
+static_assert(VK_GZ_HIST != 512 || kGzChunkWaves == 4u * VK_GZ_CHUNK_OCC, "GzLds has outgrown its LDS granules: fewer wavefronts per CU than the register budget allows");
 
 // The block start of chunk `c` (step (1) above): bit position in the file, 0 for a file's first chunk, kGzNone when the
 // chunk holds none.  The whole wavefront; wave-uniform result.
@@ -1255,6 +1306,9 @@ __global__ __launch_bounds__(64, 7) void vk_gzfind_kernel(const uint8_t* __restr
     __shared__ GzLds L;
     const uint32_t c = blockIdx.x;
     if (c >= nchunks_total) return;
+#if VK_GZ_SYMTAB
+    gz_lds_init(L);
+#endif
     const GzChunk ch = chunks[c];
     const uint64_t found = gz_find_start(L, gz, ch, c);
     if ((threadIdx.x & 63) == 0) starts[c] = found;
@@ -1271,6 +1325,9 @@ __global__ __launch_bounds__(64, VK_GZ_CHUNK_OCC) void vk_gzchunk_kernel(const u
     __shared__ uint16_t hist[kGzHist];
     const uint32_t c = blockIdx.x;
     if (c >= nchunks_total) return;
+#if VK_GZ_SYMTAB
+    gz_lds_init(L);
+#endif
     const GzChunk ch = chunks[c];
     const uint32_t j = c - ch.file_chunk0;
     uint64_t n = 0, eb = 0;
